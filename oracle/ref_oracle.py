@@ -1,0 +1,125 @@
+"""TEST INFRASTRUCTURE -- ctypes front end of oracle/_ref/liboracle_ref_p<pcols>_l<pver>.so.
+
+That library is the reference's own Fortran (physics/zm_conv.F90, geopotential.F90, modal_aer_opt.F90,
+compiled unmodified by oracle/Makefile) behind the bind(C) wrappers of oracle/ref_wrap_*.F90.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+All profile arrays are numpy float64 [ncol][pver] (interfaces [ncol][pver+1]).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_D = C.POINTER(C.c_double)
+_I = C.POINTER(C.c_int)
+
+
+def ref_lib_path(pcols: int, pver: int) -> str:
+    return os.path.join(_HERE, "_ref", f"liboracle_ref_p{pcols}_l{pver}.so")
+
+
+def have_ref(pcols: int, pver: int) -> bool:
+    return os.path.exists(ref_lib_path(pcols, pver))
+
+
+def _d(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
+    return a.ctypes.data_as(_D)
+
+
+def _i(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_I)
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class RefOracle:
+    def __init__(self, pcols: int = 16, pver: int = 32):
+        self.lib = C.CDLL(ref_lib_path(pcols, pver))
+        pc, pv = C.c_int(), C.c_int()
+        self.lib.ref_dims(C.byref(pc), C.byref(pv))
+        assert (pc.value, pv.value) == (pcols, pver)
+        self.pcols, self.pver = pcols, pver
+        self.lib.ref_zm_convi.argtypes = [C.c_int] + [C.c_double] * 6 + [C.c_int] * 4 + [C.c_double] * 3 + [C.c_int, C.c_double]
+        self.lib.ref_set_dycore.argtypes = [C.c_int]
+        self.lib.ref_set_thermo_species.argtypes = [C.c_int]
+
+    def nchunks(self, n):
+        return (n + self.pcols - 1) // self.pcols
+
+    # -- init ------------------------------------------------------------------------------------
+    def zm_convi(self, limcnv, nl):
+        self.lib.ref_zm_convi(limcnv, nl["c0_lnd"], nl["c0_ocn"], nl["ke"], nl["ke_lnd"], nl["momcu"], nl["momcd"],
+                              nl["num_cin"], nl["org"], nl["microp"], nl["no_deep_pbl"], nl["tiedke_add"],
+                              nl["capelmt"], nl["dmpdz"], nl["parcel_pbl"], nl["tau"])
+
+    # -- geopotential_t ----------------------------------------------------------------------------
+    def geopotential_t(self, piln, pmln, pint, pmid, pdel, rpdel, t, q, rair, gravit, zvir, dycore=1, nspecies=1):
+        """q: [nq][ncol][pver] (or [ncol][pver] for water vapour only)."""
+        n, pver = t.shape
+        q = _c(q)
+        if q.ndim == 2:
+            q = q[None]
+        self.lib.ref_set_dycore(dycore)
+        self.lib.ref_set_thermo_species(nspecies)
+        zi = np.zeros((n, pver + 1)); zm = np.zeros((n, pver))
+        args = [_c(a) for a in (piln, pmln, pint, pmid, pdel, rpdel, t)]
+        self.lib.ref_geopotential_t(C.c_int(n), C.c_int(q.shape[0]), *[_d(a) for a in args], _d(q), _d(_c(rair)),
+                                    C.c_double(gravit), _d(_c(zvir)), _d(zi), _d(zm))
+        return zi, zm
+
+    # -- zm_convr ----------------------------------------------------------------------------------
+    def zm_convr(self, t, qh, pblh, zm, geos, zi, pap, paph, dpp, delt, tpert, landfrac):
+        n, pver = t.shape
+        o = {}
+        for k in ("qtnd", "heat", "dlf", "cme", "zdu", "rprd", "dif", "dnlf", "dnif", "eurt", "ql",
+                  "mu", "md", "du", "eu", "ed", "dp"):
+            o[k] = np.zeros((n, pver))
+        for k in ("mcon", "pflx"):
+            o[k] = np.zeros((n, pver + 1))
+        for k in ("cape", "dsubcld", "jctop", "jcbot", "prec", "rliq", "rice"):
+            o[k] = np.zeros(n)
+        for k in ("jt", "maxg", "ideep"):
+            o[k] = np.zeros(n, dtype=np.int32)
+        o["lengath"] = np.zeros(self.nchunks(n), dtype=np.int32)
+        ins = [_c(a) for a in (t, qh, pblh, zm, geos, zi, pap, paph, dpp)]
+        self.lib.ref_zm_convr(
+            C.c_int(n), *[_d(a) for a in ins], C.c_double(delt), _d(_c(tpert)), _d(_c(landfrac)),
+            *[_d(o[k]) for k in ("qtnd", "heat", "mcon", "dlf", "pflx", "cme", "cape", "zdu", "rprd", "dif", "dnlf",
+                                 "dnif", "eurt", "ql", "mu", "md", "du", "eu", "ed", "dp", "dsubcld", "jctop",
+                                 "jcbot", "prec", "rliq", "rice")],
+            _i(o["jt"]), _i(o["maxg"]), _i(o["ideep"]), _i(o["lengath"]))
+        return o
+
+    # -- zm_conv_evap ------------------------------------------------------------------------------
+    def zm_conv_evap(self, t, pmid, pdel, q, landfrac, prdprec, cldfrc, deltat, prec):
+        n, pver = t.shape
+        o = {k: np.zeros((n, pver)) for k in ("tend_s", "tend_s_snwprd", "tend_s_snwevmlt", "tend_q", "ntprprd", "ntsnprd")}
+        o["flxprec"] = np.zeros((n, pver + 1)); o["flxsnow"] = np.zeros((n, pver + 1))
+        o["snow"] = np.zeros(n)
+        o["prec"] = _c(prec).copy()
+        ins = [_c(a) for a in (t, pmid, pdel, q, landfrac, prdprec, cldfrc)]
+        self.lib.ref_zm_conv_evap(
+            C.c_int(n), *[_d(a) for a in ins], C.c_double(deltat), _d(o["prec"]),
+            *[_d(o[k]) for k in ("tend_s", "tend_s_snwprd", "tend_s_snwevmlt", "tend_q", "snow", "ntprprd", "ntsnprd",
+                                 "flxprec", "flxsnow")])
+        return o
+
+    # -- momtran -----------------------------------------------------------------------------------
+    def momtran(self, u, v, mu, md, du, eu, ed, dp, dsubcld, jt, mx, ideep, lengath, dt):
+        n, pver = u.shape
+        winds = np.ascontiguousarray(np.stack([u, v]), dtype=np.float64)      # [2][ncol][pver]
+        o = {k: np.zeros((2, n, pver)) for k in ("dqdt", "pguall", "pgdall", "icwu", "icwd")}
+        o["seten"] = np.zeros((n, pver))
+        ins = [_c(a) for a in (mu, md, du, eu, ed, dp, dsubcld)]
+        ints = [np.ascontiguousarray(a, dtype=np.int32) for a in (jt, mx, ideep, lengath)]
+        self.lib.ref_momtran(C.c_int(n), _d(winds), *[_d(a) for a in ins], *[_i(a) for a in ints], C.c_double(dt),
+                             *[_d(o[k]) for k in ("dqdt", "pguall", "pgdall", "icwu", "icwd", "seten")])
+        return o
