@@ -1,0 +1,161 @@
+"""ctypes mirror of include/colphys.h (the C ABI).  Struct layouts must match the header field for field."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+PD = C.POINTER(C.c_double)
+PI = C.POINTER(C.c_int32)
+
+COLPHYS_MAX_PVER = 128
+DYCORE_EUL, DYCORE_FV, DYCORE_SE = 0, 1, 2
+STATUS_BRENT_NOT_CONVERGED = 1
+STATUS_DOPAER_RANGE = 2
+NCOEF, PREFR, PREFI = 5, 7, 10
+
+K_GEOPOTENTIAL, K_ZM_TRIGGER, K_ZM_PLUME, K_ZM_EVAP, K_MOMTRAN, K_AERO_SW, K_AERO_LW = range(7)
+KERNEL_NAMES = ["geopotential_t", "zm_trigger", "zm_plume", "zm_conv_evap", "momtran", "modal_aero_sw", "modal_aero_lw"]
+
+
+class ZmParams(C.Structure):
+    _fields_ = (
+        [(n, C.c_double) for n in (
+            "cpair", "epsilo", "gravit", "latice", "latvap", "tmelt", "rair", "cpwv", "cpliq", "rh2o", "cpvir", "zvir",
+            "c0_lnd", "c0_ocn", "ke", "ke_lnd", "momcu", "momcd", "tiedke_add", "capelmt", "dmpdz_param", "tau",
+            "tiedke_lnd", "entrmn", "alfadet", "tentrm", "plclmin", "cin_threshd", "parcel_hscale")]
+        + [(n, C.c_int32) for n in (
+            "limcnv", "num_cin", "zm_org", "zmconv_microp", "no_deep_pbl", "lparcel_pbl", "cam3", "reserved")]
+    )
+
+
+def make_zm_params(physconst: dict, namelist: dict, limcnv: int) -> ZmParams:
+    """What zm_convi receives (zm_conv.F90:115-120) + physconst + module defaults (:83-97,103)."""
+    p = ZmParams()
+    for k in ("cpair", "epsilo", "gravit", "latice", "latvap", "tmelt", "rair", "cpwv", "cpliq", "rh2o", "cpvir", "zvir"):
+        setattr(p, k, physconst[k])
+    for k in ("c0_lnd", "c0_ocn", "ke", "ke_lnd", "momcu", "momcd", "tiedke_add", "capelmt", "tau"):
+        setattr(p, k, namelist[k])
+    p.dmpdz_param = namelist["dmpdz"]
+    p.tiedke_lnd = 1.0
+    p.entrmn = 2.0e-4
+    p.alfadet = 0.1
+    p.tentrm = -namelist["dmpdz"]          # zm_convi resets tentrm = -dmpdz_param (:213)
+    p.plclmin = 6.0e2
+    p.cin_threshd = 0.33
+    p.parcel_hscale = 0.5
+    p.limcnv = limcnv
+    p.num_cin = namelist["num_cin"]
+    p.zm_org = namelist["org"]
+    p.zmconv_microp = namelist["microp"]
+    p.no_deep_pbl = namelist["no_deep_pbl"]
+    p.lparcel_pbl = namelist["parcel_pbl"]
+    p.cam3 = 0
+    return p
+
+
+class ZmConvrIO(C.Structure):
+    _fields_ = (
+        [(n, PD) for n in ("t", "qh", "pap", "dpp", "zm", "paph", "zi", "geos", "pblh", "tpert", "landfrac",
+                           "qtnd", "heat", "cme", "zdu", "rprd", "dlf", "ql", "dif", "dnlf", "dnif", "eurt",
+                           "mcon", "pflx", "prec", "jctop", "jcbot", "cape", "rliq", "rice",
+                           "mu", "md", "du", "eu", "ed", "dp", "dsubcld")]
+        + [(n, PI) for n in ("jt", "maxg", "ideep", "lengath", "status")]
+    )
+
+
+ZM_CONVR_IN_MID = ("t", "qh", "pap", "dpp", "zm")
+ZM_CONVR_IN_INT = ("paph", "zi")
+ZM_CONVR_IN_COL = ("geos", "pblh", "tpert", "landfrac")
+ZM_CONVR_OUT_MID = ("qtnd", "heat", "cme", "zdu", "rprd", "dlf", "ql", "dif", "dnlf", "dnif", "eurt",
+                    "mu", "md", "du", "eu", "ed", "dp")
+ZM_CONVR_OUT_INT = ("mcon", "pflx")
+ZM_CONVR_OUT_COL = ("prec", "jctop", "jcbot", "cape", "rliq", "rice", "dsubcld")
+ZM_CONVR_OUT_ICOL = ("jt", "maxg", "ideep", "status")
+ZM_CONVR_GATHERED = ("mu", "md", "du", "eu", "ed", "dp", "dsubcld", "jt", "maxg")
+
+
+class ZmConvEvapIO(C.Structure):
+    _fields_ = [(n, PD) for n in ("t", "pmid", "pdel", "q", "prdprec", "cldfrc", "landfrac", "prec",
+                                  "tend_s", "tend_s_snwprd", "tend_s_snwevmlt", "tend_q", "ntprprd", "ntsnprd",
+                                  "flxprec", "flxsnow", "snow")]
+
+
+EVAP_IN_MID = ("t", "pmid", "pdel", "q", "prdprec", "cldfrc")
+EVAP_OUT_MID = ("tend_s", "tend_s_snwprd", "tend_s_snwevmlt", "tend_q", "ntprprd", "ntsnprd")
+EVAP_OUT_INT = ("flxprec", "flxsnow")
+
+
+class MomtranIO(C.Structure):
+    _fields_ = (
+        [(n, PD) for n in ("winds", "mu", "md", "du", "eu", "ed", "dp", "dsubcld")]
+        + [(n, PI) for n in ("jt", "mx", "ideep", "lengath")]
+        + [(n, PD) for n in ("dqdt", "pguall", "pgdall", "icwu", "icwd", "seten")]
+    )
+
+
+MOMTRAN_OUT_3D = ("dqdt", "pguall", "pgdall", "icwu", "icwd")
+
+
+class AeroTables(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ("nmodes", "nspec_max", "nswbands", "nlwbands", "top_lev",
+                                  "idx_sw_diag", "idx_uv_diag", "idx_nir_diag")]
+        + [(n, C.c_double) for n in ("rhoh2o", "rga", "rair", "xrmin", "xrmax")]
+        + [("nspec", PI), ("spectype", PI)]
+        + [(n, PD) for n in ("sigmag", "specdens", "hygro", "specrefindex_sw", "specrefindex_lw",
+                             "refrtabsw", "refitabsw", "refrtablw", "refitablw",
+                             "extpsw", "abspsw", "asmpsw", "absplw", "crefwsw", "crefwlw")]
+    )
+
+
+class ModalAeroIO(C.Structure):
+    _fields_ = (
+        [(n, PD) for n in ("pdeldry", "pmid", "t", "specmmr", "dgnumwet", "qaerwat")]
+        + [("troplevchem", PI)]
+        + [(n, PD) for n in ("tauxar", "wa", "ga", "fa")]
+        + [("status", PI)]
+    )
+
+
+def dptr(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], (a.dtype, a.shape)
+    return a.ctypes.data_as(PD)
+
+
+def iptr(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"], (a.dtype, a.shape)
+    return a.ctypes.data_as(PI)
+
+
+def complex_pairs(z: np.ndarray) -> np.ndarray:
+    """complex array -> float64 [... , 2] (re, im)"""
+    return np.ascontiguousarray(np.stack([z.real, z.imag], axis=-1), dtype=np.float64)
+
+
+def build_aero_tables(props: dict, physconst: dict, keep: list) -> AeroTables:
+    """Pack synth.make_aero_props()-style tables; `keep` receives the arrays that must outlive the struct."""
+    import math
+    tb = AeroTables()
+    tb.nmodes = int(props["nmodes"]); tb.nspec_max = int(props["nspec_max"])
+    tb.nswbands = props["crefwsw"].shape[0]; tb.nlwbands = props["crefwlw"].shape[0]
+    tb.top_lev = int(props.get("top_lev", 1))
+    tb.idx_sw_diag, tb.idx_uv_diag, tb.idx_nir_diag = 10, 11, 8
+    tb.rhoh2o = physconst["rhoh2o"]; tb.rga = physconst["rga"]; tb.rair = physconst["rair"]
+    tb.xrmin = math.log(0.01e-6); tb.xrmax = math.log(25.0e-6)       # modal_aer_opt.F90:140-143
+
+    def f64(name, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64); keep.append(a); setattr(tb, name, dptr(a))
+
+    def i32(name, arr):
+        a = np.ascontiguousarray(arr, dtype=np.int32); keep.append(a); setattr(tb, name, iptr(a))
+
+    i32("nspec", props["nspec"]); i32("spectype", props["spectype"])
+    for n in ("sigmag", "specdens", "hygro", "refrtabsw", "refitabsw", "refrtablw", "refitablw",
+              "extpsw", "abspsw", "asmpsw", "absplw"):
+        f64(n, props[n])
+    f64("specrefindex_sw", complex_pairs(props["specrefindex_sw"]))
+    f64("specrefindex_lw", complex_pairs(props["specrefindex_lw"]))
+    f64("crefwsw", complex_pairs(props["crefwsw"]))
+    f64("crefwlw", complex_pairs(props["crefwlw"]))
+    return tb

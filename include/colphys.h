@@ -1,0 +1,254 @@
+/* colphys.h -- C ABI of the MI355X column-physics engine (libcolphys_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of NorESMhub/CAM-Nor-physics:
+ *
+ *   entry point                      replaces (reference file:line)
+ *   -------------------------------  -------------------------------------------------------------
+ *   colphys_init                     zm_convi                 physics/zm_conv.F90:115-227
+ *                                    (+ the physconst values zm_conv.F90:19-20 `use`s, + xrmin/xrmax
+ *                                     of modal_aer_opt_init   physics/modal_aer_opt.F90:140-143)
+ *   colphys_geopotential_t*          geopotential_t           physics/geopotential.F90:153-310
+ *   colphys_zm_convr*                zm_convr                 physics/zm_conv.F90:231-1709
+ *                                    (buoyan_dilute :4425, parcel_dilute :4824, cldprp :3024,
+ *                                     closure :4028, q1q2_pjr :4262, entropy/enthalpy/Brent :5280-5570)
+ *   colphys_zm_conv_evap*            zm_conv_evap             physics/zm_conv.F90:1712-1972
+ *   colphys_momtran*                 momtran                  physics/zm_conv.F90:2315-2715
+ *   colphys_aero_tables_set          rad_cnst_get_mode_props / rad_cnst_get_aer_props data consumed at
+ *                                    physics/modal_aer_opt.F90:717-721,759-762,1334-1355 and the water
+ *                                    refractive indices crefwsw/crefwlw :59-60,1525-1530
+ *   colphys_modal_aero_sw*           modal_aero_sw            physics/modal_aer_opt.F90:485-1212
+ *   colphys_modal_aero_lw*           modal_aero_lw            physics/modal_aer_opt.F90:1216-1469
+ *
+ * Two families of entry points:
+ *
+ *   *_dev   : every pointer is a DEVICE pointer, data already resident in HBM, layout "column-contiguous
+ *             SoA": one buffer per field, shape [ncol][pver] (interfaces [ncol][pver+1]), the column's
+ *             profile contiguous.  `stream` is a hipStream_t passed as void*.  Asynchronous: returns after
+ *             enqueueing.  This is the whole-node dispatch (every grid column one work item).
+ *
+ *   *_chunks: HOST pointers in the reference's own chunk layout -- Fortran (pcols,pver[,..],nchunks),
+ *             column index fastest -- as the ISO_C_BINDING shim (cam-nor-physics_amd/fortran/) passes the
+ *             physics_state / ptend / pbuf arrays of one or many chunks.  Packs exactly ncol(c) columns
+ *             per chunk (padding holds +inf in CAM: physics_types.F90:2143-2178), copies to the device,
+ *             runs the *_dev path, copies back, synchronises.
+ *
+ * Conventions
+ *   - fp64 throughout; level indices are int32, 1-based as in the reference.
+ *   - Gathered outputs (mu, md, du, eu, ed, dp, dsubcld, jt, maxg, ideep) keep the reference's PER-CHUNK
+ *     compaction (zm_conv.F90:926-940): gathered slot j (0-based) of chunk c lives in row c*pcols + j,
+ *     ideep holds the 1-based in-chunk column index in ascending order, lengath[c] the count.
+ *     Slots >= lengath[c] are zero-filled (the reference leaves them stale; nothing reads them:
+ *     zm_conv_intr.F90:700-706,1006-1017).
+ *   - Return value 0 = ok, < 0 = argument/runtime error (colphys_last_error()), and the per-column
+ *     status[] array carries the conditions the reference turns into endrun():
+ *       bit 0 (1): ientropy/ienthalpy did not converge  (zm_conv.F90:5401-5410, 5557-5566)
+ *       bit 1 (2): aerosol optical depth out of range    (modal_aer_opt.F90:997-1029, 1402-1437)
+ *   - No entry point retains caller pointers past its return (the *_dev ones: past stream completion).
+ *   - There is no CPU fallback: every compute entry point fails with COLPHYS_ERR_NODEVICE when no HIP
+ *     device is present.
+ */
+#ifndef COLPHYS_H
+#define COLPHYS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COLPHYS_ABI_VERSION 1
+
+#define COLPHYS_OK             0
+#define COLPHYS_ERR_ARG      (-1)
+#define COLPHYS_ERR_NODEVICE (-2)
+#define COLPHYS_ERR_HIP      (-3)
+#define COLPHYS_ERR_NOTINIT  (-4)
+#define COLPHYS_ERR_UNSUPPORTED (-5)
+
+#define COLPHYS_STATUS_BRENT_NOT_CONVERGED 1
+#define COLPHYS_STATUS_DOPAER_RANGE        2
+
+#define COLPHYS_MAX_PVER 128
+
+/* dycore_kind for geopotential_t (geopotential.F90:217,222,227) */
+#define COLPHYS_DYCORE_EUL 0   /* hkl = pdel/pmid,            tvfac = 1 + zvir*q                    */
+#define COLPHYS_DYCORE_FV  1   /* 'LR'/'FV3': hkl = dlnp,     tvfac = 1 + zvir*q                    */
+#define COLPHYS_DYCORE_SE  2   /* 'SE'/'MPAS': hkl = pdel/pmid, generalised virtual temperature     */
+
+/* Everything zm_convi copies into SAVEd module variables (zm_conv.F90:42-108,145-183), the physconst
+ * values the module `use`s (:19-20), and the module-level tunables with their defaults (:83-97,103).
+ * Filled by the host from ITS physconst / namelist -- nothing here is hard-coded in the kernels. */
+typedef struct colphys_zm_params {
+    /* physconst */
+    double cpair, epsilo, gravit, latice, latvap, tmelt, rair, cpwv, cpliq, rh2o, cpvir, zvir;
+    /* zm_convi arguments */
+    double c0_lnd, c0_ocn, ke, ke_lnd, momcu, momcd, tiedke_add, capelmt, dmpdz_param, tau;
+    /* module tunables (defaults in colphys_zm_params_defaults) */
+    double tiedke_lnd, entrmn, alfadet, tentrm, plclmin, cin_threshd, parcel_hscale;
+    int32_t limcnv, num_cin, zm_org, zmconv_microp, no_deep_pbl, lparcel_pbl;
+    int32_t cam3;           /* cam_physpkg_is('cam3'): non-dilute buoyan; unsupported (zm_conv.F90:871) */
+    int32_t reserved;
+} colphys_zm_params;
+
+/* module-level defaults of zm_conv.F90:83-97,103; tentrm = -dmpdz_param as zm_convi resets it (:213) */
+void colphys_zm_params_defaults(colphys_zm_params *p);
+
+int  colphys_abi_version(void);
+const char *colphys_last_error(void);
+int  colphys_device_count(void);
+
+/* Select the HIP device of this process (one process per GPU) and upload parameters; builds the
+ * 1-K saturation table zm_conv_evap's qsat uses.  May be called again to change parameters. */
+int  colphys_init(int device, const colphys_zm_params *p);
+int  colphys_finalize(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * geopotential_t  (geopotential.F90:153-156)
+ *   q is [nq][ncol][pver]; species 0 is water vapour; for COLPHYS_DYCORE_SE the first `nspecies`
+ *   entries are the thermodynamically active species (air_composition).
+ * ------------------------------------------------------------------------------------------------- */
+int colphys_geopotential_t_dev(int ncol, int pver, int dycore_kind, int nq, int nspecies,
+                               const double *piln, const double *pmln, const double *pint,
+                               const double *pmid, const double *pdel, const double *rpdel,
+                               const double *t, const double *q, const double *rair, double gravit,
+                               const double *zvir, double *zi, double *zm, void *stream);
+
+int colphys_geopotential_t_chunks(int nchunks, int pcols, int pver, const int32_t *ncol,
+                                  int dycore_kind, int nq, int nspecies,
+                                  const double *piln, const double *pmln, const double *pint,
+                                  const double *pmid, const double *pdel, const double *rpdel,
+                                  const double *t, const double *q, const double *rair, double gravit,
+                                  const double *zvir, double *zi, double *zm);
+
+/* ---------------------------------------------------------------------------------------------------
+ * zm_convr  (zm_conv.F90:231-244; intents :362-423)
+ *   full-layout outputs  [ncol][pver]  : qtnd heat cme zdu rprd dlf ql dif dnlf dnif eurt
+ *                        [ncol][pver+1]: mcon pflx
+ *                        [ncol]        : prec jctop jcbot cape rliq rice
+ *   gathered-layout outputs            : mu md du eu ed dp [ncol][pver]; dsubcld [ncol];
+ *                                        jt maxg ideep [ncol] int32; lengath [nchunks]
+ *   pcols = chunk width used for the gathered layout (ncol need not be a multiple of it).
+ *   delt = 0.5*ztodt exactly as zm_conv_tend passes it (zm_conv_intr.F90:666).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct colphys_zm_convr_io {
+    /* in */
+    const double *t, *qh, *pap, *dpp, *zm;        /* [ncol][pver]   */
+    const double *paph, *zi;                      /* [ncol][pver+1] */
+    const double *geos, *pblh, *tpert, *landfrac; /* [ncol]         */
+    /* out, full layout */
+    double *qtnd, *heat, *cme, *zdu, *rprd, *dlf, *ql, *dif, *dnlf, *dnif, *eurt; /* [ncol][pver] */
+    double *mcon, *pflx;                          /* [ncol][pver+1] */
+    double *prec, *jctop, *jcbot, *cape, *rliq, *rice; /* [ncol]    */
+    /* out, gathered layout */
+    double *mu, *md, *du, *eu, *ed, *dp;          /* [ncol][pver]   */
+    double *dsubcld;                              /* [ncol]         */
+    int32_t *jt, *maxg, *ideep;                   /* [ncol]         */
+    int32_t *lengath;                             /* [nchunks]      */
+    int32_t *status;                              /* [ncol]         */
+} colphys_zm_convr_io;
+
+int colphys_zm_convr_dev(int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io *io, void *stream);
+int colphys_zm_convr_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, double delt,
+                            const colphys_zm_convr_io *io);
+
+/* ---------------------------------------------------------------------------------------------------
+ * zm_conv_evap  (zm_conv.F90:1712-1717); prdsnow absent => old_snow (:1789-1794)
+ *   prec is in/out (m/s).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct colphys_zm_conv_evap_io {
+    const double *t, *pmid, *pdel, *q, *prdprec, *cldfrc;   /* [ncol][pver] */
+    const double *landfrac;                                 /* [ncol]       */
+    double *prec;                                           /* [ncol] inout */
+    double *tend_s, *tend_s_snwprd, *tend_s_snwevmlt, *tend_q, *ntprprd, *ntsnprd; /* [ncol][pver] */
+    double *flxprec, *flxsnow;                              /* [ncol][pver+1] */
+    double *snow;                                           /* [ncol]       */
+} colphys_zm_conv_evap_io;
+
+int colphys_zm_conv_evap_dev(int ncol, int pver, double deltat, const colphys_zm_conv_evap_io *io, void *stream);
+int colphys_zm_conv_evap_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, double deltat,
+                                const colphys_zm_conv_evap_io *io);
+
+/* ---------------------------------------------------------------------------------------------------
+ * momtran  (zm_conv.F90:2315-2319) for the two wind components (ncnst = 2, domomtran = .true.)
+ *   winds and the 3-D outputs are [2][ncol][pver]; mass fluxes etc. are the gathered outputs of zm_convr.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct colphys_momtran_io {
+    const double *winds;                             /* [2][ncol][pver] */
+    const double *mu, *md, *du, *eu, *ed, *dp;       /* gathered [ncol][pver] */
+    const double *dsubcld;                           /* gathered [ncol] */
+    const int32_t *jt, *mx, *ideep;                  /* gathered [ncol] */
+    const int32_t *lengath;                          /* [nchunks] */
+    double *dqdt, *pguall, *pgdall, *icwu, *icwd;    /* [2][ncol][pver] */
+    double *seten;                                   /* [ncol][pver] */
+} colphys_momtran_io;
+
+int colphys_momtran_dev(int ncol, int pver, int pcols, double dt, const colphys_momtran_io *io, void *stream);
+int colphys_momtran_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, double dt,
+                           const colphys_momtran_io *io);
+
+/* ---------------------------------------------------------------------------------------------------
+ * modal aerosol optics  (modal_aer_opt.F90)
+ *   Tables (host pointers, copied to the device once):
+ *     sigmag[nmodes]; nspec[nmodes]; specdens, hygro [nmodes][nspec_max]; spectype [nmodes][nspec_max]
+ *       (0 sulfate,1 p-organic,2 s-organic,3 black-c,4 dust,5 seasalt, -1 other);
+ *     specrefindex_sw [nmodes][nspec_max][nswbands][2] (re,im); specrefindex_lw likewise;
+ *     refrtabsw [nmodes][nswbands][prefr]; refitabsw [nmodes][nswbands][prefi]; (lw likewise)
+ *     extpsw/abspsw/asmpsw [nmodes][nswbands][prefi][prefr][ncoef] (= Fortran (ncoef,prefr,prefi,nsw));
+ *     absplw [nmodes][nlwbands][prefi][prefr][ncoef]; crefwsw [nswbands][2]; crefwlw [nlwbands][2].
+ * ------------------------------------------------------------------------------------------------- */
+#define COLPHYS_NCOEF 5
+#define COLPHYS_PREFR 7
+#define COLPHYS_PREFI 10
+
+typedef struct colphys_aero_tables {
+    int32_t nmodes, nspec_max, nswbands, nlwbands;
+    int32_t top_lev;                 /* clim_modal_aero_top_lev, 1-based */
+    int32_t idx_sw_diag, idx_uv_diag, idx_nir_diag;   /* radconstants, 1-based */
+    double  rhoh2o, rga, rair;       /* physconst values modal_aer_opt uses (:18) */
+    double  xrmin, xrmax;            /* log(rmmin), log(rmmax) (:140-143) */
+    const int32_t *nspec, *spectype;
+    const double *sigmag, *specdens, *hygro;
+    const double *specrefindex_sw, *specrefindex_lw;
+    const double *refrtabsw, *refitabsw, *refrtablw, *refitablw;
+    const double *extpsw, *abspsw, *asmpsw, *absplw;
+    const double *crefwsw, *crefwlw;
+} colphys_aero_tables;
+
+int colphys_aero_tables_set(const colphys_aero_tables *tb);
+
+typedef struct colphys_modal_aero_io {
+    const double *pdeldry, *pmid, *t;     /* [ncol][pver] (pmid, t only used by the SW diagnostics) */
+    const double *specmmr;                /* [nmodes][nspec_max][ncol][pver] */
+    const double *dgnumwet, *qaerwat;     /* [nmodes][ncol][pver] */
+    const int32_t *troplevchem;           /* [ncol] (SW diagnostics only; may be NULL) */
+    /* SW out: [ncol][nswbands][pver+1] (level index 0..pver as in the reference's (pcols,0:pver,nswbands)) */
+    double *tauxar, *wa, *ga, *fa;
+    /* LW out: [ncol][nlwbands][pver]; pass through tauxar (wa/ga/fa NULL) */
+    int32_t *status;                      /* [ncol] */
+} colphys_modal_aero_io;
+
+int colphys_modal_aero_sw_dev(int ncol, int pver, const colphys_modal_aero_io *io, void *stream);
+int colphys_modal_aero_lw_dev(int ncol, int pver, const colphys_modal_aero_io *io, void *stream);
+int colphys_modal_aero_sw_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io);
+int colphys_modal_aero_lw_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Measurement helper: average device time (ms) of each kernel family since the last reset, measured
+ * with HIP events on the launch stream when profiling is switched on (bench.py's roofline leg).
+ * ------------------------------------------------------------------------------------------------- */
+#define COLPHYS_K_GEOPOTENTIAL 0
+#define COLPHYS_K_ZM_TRIGGER   1
+#define COLPHYS_K_ZM_PLUME     2
+#define COLPHYS_K_ZM_EVAP      3
+#define COLPHYS_K_MOMTRAN      4
+#define COLPHYS_K_AERO_SW      5
+#define COLPHYS_K_AERO_LW      6
+#define COLPHYS_K_COUNT        8
+int colphys_profile_enable(int on);
+int colphys_profile_reset(void);
+int colphys_profile_get(int kernel, double *avg_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLPHYS_H */

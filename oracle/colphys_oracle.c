@@ -1,0 +1,1334 @@
+/* TEST INFRASTRUCTURE -- CPU restatement (plain C) of the reference's ZM deep convection + geopotential
+ * path.  See colphys_oracle.h for the rules on who may use it and how it is pinned.
+ *
+ * One grid column at a time, same operation order as the Fortran, no FMA contraction (Makefile).
+ * Arrays are 1-based (index k = 1..pver, k = 1 the model top) to keep the level arithmetic identical to
+ * the reference.  All line numbers are /root/reference/physics/zm_conv.F90 unless another file is named.
+ *
+ * Active configuration (hard-wired in the reference, zm_conv.F90:75-78):
+ *   second_call = retrigger = use_cin = tht_tweaks = .true.
+ * Out of scope: zm_org, zmconv_microp, cam3 (non-dilute buoyan).
+ */
+#include "colphys_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NL (COLPHYS_MAX_PVER + 2)
+
+static colphys_zm_params P;
+/* SAVEd module variables of zm_conv.F90:42-108 as zm_convi derives them (:145-155) */
+static double rl, cpres, rgrav, rgas, grav, cp, tfreez, eps1, dcol;
+
+/* ------------------------------------------------------------------------------------------------
+ * L0 seams -- identical to oracle/stubs/l0_arithmetic.F90 (the specification; parity unpinned vs CAM)
+ * ---------------------------------------------------------------------------------------------- */
+#define TBOIL 373.16
+#define H2OTRIP 273.16
+#define TTRICE 20.0
+#define TMIN_TBL 127.16
+#define TMAX_TBL 375.16
+#define PLENEST 249
+static double estbl[PLENEST + 1];
+
+static double svp_water(double t)
+{
+    return pow(10.0, -7.90298 * (TBOIL / t - 1.0) + 5.02808 * log10(TBOIL / t)
+                         - 1.3816e-7 * (pow(10.0, 11.344 * (1.0 - t / TBOIL)) - 1.0)
+                         + 8.1328e-3 * (pow(10.0, -3.49149 * (TBOIL / t - 1.0)) - 1.0)
+                         + log10(1013.246)) * 100.0;
+}
+
+static double svp_ice(double t)
+{
+    return pow(10.0, -9.09718 * (H2OTRIP / t - 1.0) - 3.56654 * log10(H2OTRIP / t)
+                         + 0.876793 * (1.0 - t / H2OTRIP) + log10(6.1071)) * 100.0;
+}
+
+static double svp_trans(double t)
+{
+    double es = 0.0;
+    if (t >= (P.tmelt - TTRICE)) es = svp_water(t);
+    if (t < P.tmelt) {
+        double esice = svp_ice(t), weight;
+        if ((P.tmelt - t) > TTRICE) weight = 1.0;
+        else weight = (P.tmelt - t) / TTRICE;
+        es = weight * esice + (1.0 - weight) * es;
+    }
+    return es;
+}
+
+static double svp_to_qsat(double es, double p)
+{
+    if ((p - es) <= 0.0) return 1.0;
+    return P.epsilo * es / (p - (1.0 - P.epsilo) * es);
+}
+
+void oracle_qsat_water(double t, double p, double *es, double *qs)
+{
+    double e = svp_water(t);
+    *qs = svp_to_qsat(e, p);
+    *es = fmin(e, p);
+}
+
+void oracle_qsat_table(double t, double p, double *es, double *qs)
+{
+    double t_tmp = fmax(fmin(t, TMAX_TBL) - TMIN_TBL, 0.0);
+    int i = (int)t_tmp + 1;
+    double e;
+    if (i < PLENEST) {
+        double weight = fmin(t_tmp - trunc(t_tmp), 1.0);
+        e = (1.0 - weight) * estbl[i] + weight * estbl[i + 1];
+    } else {
+        e = estbl[PLENEST];
+    }
+    *qs = svp_to_qsat(e, p);
+    *es = fmin(e, p);
+}
+
+/* qsat_hPa :5421-5437 */
+static void qsat_hPa(double t, double p, double *es, double *qm)
+{
+    oracle_qsat_water(t, p * 100.0, es, qm);
+    *es = *es * 0.01;
+}
+
+void oracle_init(const colphys_zm_params *p)
+{
+    P = *p;
+    /* zm_convi :145-155 */
+    tfreez = P.tmelt;
+    eps1 = P.epsilo;
+    rl = P.latvap;
+    cpres = P.cpair;
+    rgrav = 1.0 / P.gravit;
+    rgas = P.rair;
+    grav = P.gravit;
+    cp = cpres;
+    dcol = (P.cpliq - P.cpwv) / P.latvap;
+    for (int i = 1; i <= PLENEST; ++i) estbl[i] = svp_trans(TMIN_TBL + (double)(i - 1));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * entropy :5280-5300, enthalpy :5440-5457
+ * ---------------------------------------------------------------------------------------------- */
+double oracle_entropy(double TK, double p, double qtot)
+{
+    const double pref = 1000.0;
+    double L = rl - (P.cpliq - P.cpwv) * (TK - tfreez);
+    double est, qst;
+    qsat_hPa(TK, p, &est, &qst);
+    double qv = fmin(qtot, qst);
+    double e = qv * p / (eps1 + qv);
+    return (cpres + qtot * P.cpliq) * log(TK / tfreez) - rgas * log((p - e) / pref) + L * qv / TK
+           - qv * P.rh2o * log(qv / qst);
+}
+
+double oracle_enthalpy(double TK, double p, double qtot, double z)
+{
+    double L = rl - (P.cpliq - P.cpwv) * (TK - tfreez);
+    double est, qst;
+    qsat_hPa(TK, p, &est, &qst);
+    double qv = fmin(qtot, qst);
+    return (cpres + qtot * P.cpliq) * TK + L * qv + (1.0 + qtot) * grav * z;
+}
+
+/* ientropy :5304-5414 / ienthalpy :5460-5570 -- Brent's method; kind 0 = entropy, 1 = enthalpy.
+ * Returns 0 if converged. */
+static int invert_brent(int kind, double s, double p, double z, double qt, double *T, double *qst, double Tfg)
+{
+#define FEVAL(x) ((kind ? oracle_enthalpy((x), p, qt, z) : oracle_entropy((x), p, qt)) - s)
+    const int LOOPMAX = 100;
+    const double EPS = 3.e-8;
+    double a, b, c, d = 0.0, ebr = 0.0, fa, fb, fc, pbr, qbr, rbr, sbr, tol1, xm, tol;
+    int converged = 0;
+
+    a = Tfg - 10;
+    b = Tfg + 10;
+    fa = FEVAL(a);
+    fb = FEVAL(b);
+    c = b;
+    fc = fb;
+    tol = 0.001;
+
+    for (int i = 0; i <= LOOPMAX; ++i) {
+        if ((fb > 0.0 && fc > 0.0) || (fb < 0.0 && fc < 0.0)) {
+            c = a; fc = fa; d = b - a; ebr = d;
+        }
+        if (fabs(fc) < fabs(fb)) {
+            a = b; b = c; c = a; fa = fb; fb = fc; fc = fa;
+        }
+        tol1 = 2.0 * EPS * fabs(b) + 0.5 * tol;
+        xm = 0.5 * (c - b);
+        converged = (fabs(xm) <= tol1 || fb == 0.0);
+        if (converged) break;
+
+        if (fabs(ebr) >= tol1 && fabs(fa) > fabs(fb)) {
+            sbr = fb / fa;
+            if (a == c) {
+                pbr = 2.0 * xm * sbr;
+                qbr = 1.0 - sbr;
+            } else {
+                qbr = fa / fc;
+                rbr = fb / fc;
+                pbr = sbr * (2.0 * xm * qbr * (qbr - rbr) - (b - a) * (rbr - 1.0));
+                qbr = (qbr - 1.0) * (rbr - 1.0) * (sbr - 1.0);
+            }
+            if (pbr > 0.0) qbr = -qbr;
+            pbr = fabs(pbr);
+            if (2.0 * pbr < fmin(3.0 * xm * qbr - fabs(tol1 * qbr), fabs(ebr * qbr))) {
+                ebr = d; d = pbr / qbr;
+            } else {
+                d = xm; ebr = d;
+            }
+        } else {
+            d = xm; ebr = d;
+        }
+        a = b;
+        fa = fb;
+        b = b + ((fabs(d) > tol1) ? d : copysign(tol1, xm));
+        fb = FEVAL(b);
+    }
+    *T = b;
+    double est;
+    qsat_hPa(*T, p, &est, qst);
+    return converged ? 0 : 1;
+#undef FEVAL
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * parcel_dilute :4824-5277 (one column)
+ * ---------------------------------------------------------------------------------------------- */
+static int parcel_dilute(int pver, int msg, int klaunch, const double *p, const double *z, const double *t,
+                         const double *q, double tpert, double *tp, double *tpv, double *qstp, double *pl,
+                         double *tl, double ql, int *lcl, const double *dmpdz)
+{
+    double tmix[NL], qtmix[NL], qsmix[NL], smix[NL], xsh2o[NL], ds_xsh2o[NL], ds_freeze[NL];
+    double zl = 0.0, mp = 0.0, qtp = 0.0, sp = 0.0, sp0 = 0.0, qtp0 = 0.0, mp0 = 0.0;
+    double new_s = 0.0, new_q = 0.0, est;
+    const double lwmax = 1.e-3, tscool = 0.0;
+    const int nit_lheat = 2;
+    int status = 0;
+
+    for (int k = 0; k < NL; ++k) { qtmix[k] = 0.0; smix[k] = 0.0; tmix[k] = 0.0; qsmix[k] = 0.0; }
+
+    /* entrainment loop :4997-5148 */
+    for (int k = pver; k >= msg + 1; --k) {
+        if (k == klaunch) {
+            if (P.lparcel_pbl) {                       /* :5004-5012 */
+                qtp0 = ql;
+                sp0 = oracle_enthalpy(*tl, *pl, qtp0, zl);
+            } else {                                   /* :5015-5018 */
+                qtp0 = q[k];
+                sp0 = oracle_enthalpy(t[k], p[k], qtp0, z[k]);
+            }
+            mp0 = 1.0;
+            smix[k] = sp0;
+            qtmix[k] = qtp0;
+            tmix[k] = t[k];                            /* :5030-5031 */
+            qsat_hPa(tmix[k], p[k], &est, &qsmix[k]);
+        }
+        if (k < klaunch) {
+            double dp = (p[k] - p[k + 1]);
+            double qtenv = 0.5 * (q[k] + q[k + 1]);
+            double tenv = 0.5 * (t[k] + t[k + 1]);
+            double penv = 0.5 * (p[k] + p[k + 1]);
+            double zenv = 0.5 * (z[k] + z[k + 1]);
+            double senv = oracle_enthalpy(tenv, penv, qtenv, zenv);
+            double dpdz = -(penv * grav) / (rgas * tenv);
+            double dzdp = 1.0 / dpdz;
+            double dmpdp = dmpdz[k] * dzdp;            /* :5078 */
+
+            sp = sp - dmpdp * dp * senv;               /* :5086-5088 */
+            qtp = qtp - dmpdp * dp * qtenv;
+            mp = mp - dmpdp * dp;
+
+            smix[k] = (sp0 + sp) / (mp0 + mp);
+            qtmix[k] = (qtp0 + qtp) / (mp0 + mp);
+
+            double tfguess = tmix[k + 1];
+            status |= invert_brent(1, smix[k], p[k], z[k], qtmix[k], &tmix[k], &qsmix[k], tfguess); /* :5102 */
+
+            if (qsmix[k] <= qtmix[k] && qsmix[k + 1] > qtmix[k + 1]) {   /* :5111-5133 */
+                *lcl = k;
+                double qxsk = qtmix[k] - qsmix[k];
+                double qxskp1 = qtmix[k + 1] - qsmix[k + 1];
+                double dqxsdp = (qxsk - qxskp1) / dp;
+                *pl = p[k + 1] - qxskp1 / dqxsdp;
+                zl = z[k + 1] - qxskp1 / dqxsdp * dzdp;
+                double dsdp = (smix[k] - smix[k + 1]) / dp;
+                double dqtdp = (qtmix[k] - qtmix[k + 1]) / dp;
+                double slcl = smix[k + 1] + dsdp * (*pl - p[k + 1]);
+                double qtlcl = qtmix[k + 1] + dqtdp * (*pl - p[k + 1]);
+                double qslcl;
+                tfguess = tmix[k];
+                status |= invert_brent(1, slcl, *pl, zl, qtlcl, tl, &qslcl, tfguess);
+            }
+        }
+    }
+
+    for (int k = 0; k < NL; ++k) { xsh2o[k] = 0.0; ds_xsh2o[k] = 0.0; ds_freeze[k] = 0.0; }
+
+    /* precipitation / freezing loop :5175-5273 */
+    for (int k = pver; k >= msg + 1; --k) {
+        if (k == klaunch) {
+            tp[k] = tmix[k];
+            qstp[k] = q[k];
+            tpv[k] = (tp[k] + tpert) * (1.0 + qstp[k] / eps1) / (1.0 + qstp[k]);   /* :5194 */
+        }
+        if (k < klaunch) {
+            smix[k] = oracle_entropy(tmix[k], p[k], qtmix[k]);                       /* :5205 */
+            for (int ii = 0; ii <= nit_lheat - 1; ++ii) {
+                xsh2o[k] = fmax(0.0, qtmix[k] - qsmix[k] - lwmax);
+                ds_xsh2o[k] = ds_xsh2o[k + 1] - P.cpliq * log(tmix[k] / tfreez) * fmax(0.0, (xsh2o[k] - xsh2o[k + 1]));
+                if (tmix[k] <= tfreez + tscool && ds_freeze[k + 1] == 0.0) {
+                    ds_freeze[k] = (P.latice / tmix[k]) * fmax(0.0, qtmix[k] - qsmix[k] - xsh2o[k]);
+                }
+                if (tmix[k] <= tfreez + tscool && ds_freeze[k + 1] != 0.0) {
+                    ds_freeze[k] = ds_freeze[k + 1] + (P.latice / tmix[k]) * fmax(0.0, (qsmix[k + 1] - qsmix[k]));
+                }
+                new_s = smix[k] + ds_xsh2o[k] + ds_freeze[k];
+                new_q = qtmix[k] - xsh2o[k];
+                double tfguess = tmix[k];
+                status |= invert_brent(0, new_s, p[k], 0.0, new_q, &tmix[k], &qsmix[k], tfguess);   /* :5239 */
+            }
+            tp[k] = tmix[k];
+            if (new_q > qsmix[k]) qstp[k] = qsmix[k];
+            else qstp[k] = new_q;
+            tpv[k] = (tp[k] + tpert) * (1.0 + qstp[k] / eps1) / (1.0 + new_q);       /* :5263 */
+        }
+    }
+    return status;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * buoyan_dilute :4425-4819 (one column)
+ *   zi = interface height above the surface as passed to zm_convr, zs = geos/g
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    double tp[NL], qstp[NL], tl, cape, cin;
+    int lcl, lel, lon, mx, status;
+} buoy_out;
+
+static void buoyan_dilute(int pver, int msg, const double *q, const double *t, const double *p, const double *z,
+                          const double *pf, double pblt, const double *zi, double zs, double tpert,
+                          const double *dmpdz, double cin_in, buoy_out *o)
+{
+    double capeten[6], cinten[6], tv[NL], tpv[NL], buoy[NL];
+    int lelten[6], knt;
+    double hmax, pl, ql;
+    int plge600;
+    const int npblt = (int)lround(pblt);
+
+    for (int n = 1; n <= 5; ++n) { lelten[n] = pver; capeten[n] = 0.0; cinten[n] = 0.0; }
+    o->lon = (pver < npblt + 2) ? pver : npblt + 2;          /* :4578 */
+    knt = 0;
+    o->lel = pver;
+    o->mx = o->lon;
+    o->cape = 0.0;
+    o->cin = cin_in;             /* intent(out) but only assigned when a CAPE candidate wins (:4806) */
+    hmax = 0.0;
+    double pbl_dz = z[npblt] - zs;                             /* :4586-4588 */
+    double parcel_dz = fmax(zi[pver], P.parcel_hscale * pbl_dz);
+    double parcel_ztop = parcel_dz + zs;
+    double parcel_hdp = 0.0, parcel_dp = 0.0, parcel_qdp = 0.0, hpar = 0.0, qpar = 0.0;
+
+    for (int k = 1; k <= pver; ++k) {
+        o->tp[k] = t[k];
+        o->qstp[k] = q[k];
+        tv[k] = t[k] * (1.0 + q[k] / eps1) / (1.0 + q[k]);    /* :4604 */
+        tpv[k] = tv[k];
+        buoy[k] = 0.0;
+    }
+
+    if (P.lparcel_pbl) {                                       /* :4638-4673 */
+        int ipar = pver;
+        for (int k = pver; k >= msg + 1; --k) {
+            if (zi[k + 1] <= parcel_dz) {
+                double hmn_lev = (cp + q[k] * P.cpliq) * t[k] / (1.0 + q[k])
+                                 + (1.0 + q[k] / eps1) / (1.0 + q[k]) * grav * z[k]
+                                 + (rl - (P.cpliq - P.cpwv) * (t[k] - tfreez)) * q[k];
+                double dp_lev = pf[k + 1] - pf[k];
+                double hmn_zdp = hmn_lev * dp_lev;
+                double q_zdp = q[k] * dp_lev;
+                double dp_zfrac;
+                ipar = k;
+                if (k == pver) dp_zfrac = 1.0;
+                else dp_zfrac = fmin(1.0, (parcel_dz - zi[k + 1]) / (zi[k] - zi[k + 1]));
+                parcel_hdp = parcel_hdp + hmn_zdp * dp_zfrac;
+                parcel_qdp = parcel_qdp + q_zdp * dp_zfrac;
+                parcel_dp = parcel_dp + dp_lev * dp_zfrac;
+            }
+        }
+        hpar = parcel_hdp / parcel_dp;
+        qpar = parcel_qdp / parcel_dp;
+        o->mx = ipar;
+    } else {                                                   /* :4677-4689 */
+        for (int k = pver; k >= msg + 1; --k) {
+            double hmn = (cp + q[k] * P.cpliq) * t[k] / (1.0 + q[k])
+                         + (1.0 + q[k] / eps1) / (1.0 + q[k]) * grav * z[k]
+                         + (rl - (P.cpliq - P.cpwv) * (t[k] - tfreez)) * q[k];
+            if (k >= npblt && k <= o->lon && hmn > hmax) {
+                hmax = hmn;
+                o->mx = k;
+            }
+        }
+    }
+
+    if (P.lparcel_pbl) {                                       /* :4703-4708 */
+        o->lcl = o->mx;
+        o->tl = (hpar - rl * qpar - grav * parcel_ztop) / cp;
+        ql = qpar;
+        pl = p[o->mx];
+    } else {                                                   /* :4712-4717 */
+        o->lcl = o->mx;
+        o->tl = t[o->mx];
+        ql = q[o->mx];
+        pl = p[o->mx];
+    }
+
+    o->status |= parcel_dilute(pver, msg, o->mx, p, z, t, q, tpert, o->tp, tpv, o->qstp, &pl, &o->tl, ql, &o->lcl, dmpdz);
+
+    plge600 = (pl >= P.plclmin);                               /* :4743 */
+
+    for (int k = pver; k >= msg + 1; --k) {                    /* :4749-4765 */
+        if (k <= o->mx && plge600) {
+            tv[k] = t[k] * (1.0 + q[k] / eps1) / (1.0 + q[k]);
+            buoy[k] = tpv[k] - tv[k] + P.tiedke_add;
+        } else {
+            o->qstp[k] = q[k];
+            o->tp[k] = t[k];
+            tpv[k] = tv[k];
+        }
+    }
+
+    for (int k = msg + 2; k <= pver; ++k) {                    /* :4773-4782 */
+        if (k < o->lcl && plge600) {
+            if (buoy[k + 1] > 0.0 && buoy[k] <= 0.0) {
+                knt = (P.num_cin < knt + 1) ? P.num_cin : knt + 1;
+                lelten[knt] = k;
+            }
+        }
+    }
+
+    for (int n = 1; n <= P.num_cin; ++n) {                     /* :4785-4796 */
+        for (int k = msg + 1; k <= pver; ++k) {
+            if (plge600 && k <= o->mx && k > lelten[n]) {
+                capeten[n] = capeten[n] + rgas * buoy[k] * log(pf[k + 1] / pf[k]);
+                cinten[n] = cinten[n] - rgas * fmin(buoy[k], 0.0) * log(pf[k + 1] / pf[k]);
+            }
+        }
+    }
+
+    for (int n = 1; n <= P.num_cin; ++n) {                     /* :4802-4810 */
+        if (capeten[n] > o->cape) {
+            o->cape = capeten[n];
+            o->cin = cinten[n];
+            o->lel = lelten[n];
+        }
+    }
+    o->cape = fmax(o->cape, 0.0);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * cldprp :3024-4026 (one gathered column, non-microphysics path)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    double mu[NL], eu[NL], du[NL], md[NL], ed[NL], sd[NL], qd[NL], mc[NL], qu[NL], su[NL], qst[NL], hmn[NL],
+        hsat[NL], ql[NL], cmeg[NL], pflx[NL], evp[NL], cu[NL], rprd[NL], qcde[NL];
+    int jt, jlcl, j0, jd;
+} cld_out;
+
+static void cldprp(int pver, int msg, const double *q, const double *t, const double *p, const double *z,
+                   const double *s, const double *zf, const double *shat, const double *qhat, int jb, int lel,
+                   double landfrac, cld_out *o)
+{
+    double gamma[NL], dz[NL], iprm[NL], hu[NL], hd[NL], eps[NL], f[NL], k1[NL], i2[NL], ihat[NL], i3[NL], idag[NL],
+        i4[NL], qsthat[NL], hsthat[NL], gamhat[NL], qds[NL], mcp[NL], mrd[NL], mrl[NL], tu[NL], td[NL];
+    double hmin, expdif = 0.0, expnum = 0.0, ftemp = 0.0, eps0, rmue, zuef, zdef, epsm = 0.0, ratmjb, est, totpcp,
+           totevp, alfa, ql1, estu, qstu, small, mdt, c0mask, tiedke_msk;
+    const int mx = jb;
+    int doit, done;
+    const double rd = rgas;
+    const double zvir = P.zvir, cpvir = P.cpvir, tmelt = P.tmelt;
+
+    for (int k = 0; k < NL; ++k) { tu[k] = 0.0; td[k] = 0.0; ihat[k] = idag[k] = iprm[k] = 0.0; }
+
+    c0mask = P.c0_ocn * (1.0 - landfrac) + P.c0_lnd * landfrac;                 /* :3239-3240 */
+    tiedke_msk = P.tiedke_add * (1.0 - landfrac) + P.tiedke_lnd * landfrac;
+
+    for (int k = 1; k <= pver; ++k) dz[k] = zf[k] - zf[k + 1];
+
+    o->pflx[1] = 0;
+    for (int k = 1; k <= pver; ++k) {                                            /* :3256-3314 */
+        k1[k] = 0.0; i2[k] = 0.0; i3[k] = 0.0; i4[k] = 0.0;
+        o->mu[k] = 0.0; f[k] = 0.0; eps[k] = 0.0; o->eu[k] = 0.0; o->du[k] = 0.0; o->ql[k] = 0.0; o->cu[k] = 0.0;
+        o->evp[k] = 0.0; o->cmeg[k] = 0.0; qds[k] = q[k]; o->md[k] = 0.0; o->ed[k] = 0.0; o->sd[k] = s[k];
+        o->qd[k] = q[k]; o->mc[k] = 0.0; o->qu[k] = q[k]; o->su[k] = s[k];
+        qsat_hPa(t[k], p[k], &est, &o->qst[k]);
+        if (p[k] - est <= 0.0) o->qst[k] = 1.0;
+        mrd[k] = (1.0 + zvir * q[k]) * rd;
+        mcp[k] = (1.0 + cpvir * q[k]) * cp;
+        mrl[k] = (1.0 - dcol * (t[k] - tmelt)) * rl;
+        gamma[k] = o->qst[k] * (1.0 + o->qst[k] / eps1) * eps1 * mrl[k] / (mrd[k] * (t[k] * t[k])) * mrl[k] / mcp[k];
+        o->hmn[k] = mcp[k] * t[k] + grav * z[k] + mrl[k] * q[k];
+        o->hsat[k] = mcp[k] * t[k] + grav * z[k] + mrl[k] * o->qst[k];
+        hu[k] = o->hmn[k];
+        hd[k] = o->hmn[k];
+        o->rprd[k] = 0.0;
+        o->qcde[k] = 0.0;
+        td[k] = (hd[k] - grav * zf[k] - (1.0 + dcol * tmelt) * rl * qds[k])
+                / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * qds[k]));
+    }
+
+    for (int k = 1; k <= msg + 1; ++k) {                                         /* :3349-3355 */
+        hsthat[k] = o->hsat[k]; qsthat[k] = o->qst[k]; gamhat[k] = gamma[k];
+    }
+    totpcp = 0.0;
+    totevp = 0.0;
+    for (int k = msg + 2; k <= pver; ++k) {                                      /* :3360-3378 */
+        if (fabs(o->qst[k - 1] - o->qst[k]) > 1.E-6)
+            qsthat[k] = log(o->qst[k - 1] / o->qst[k]) * o->qst[k - 1] * o->qst[k] / (o->qst[k - 1] - o->qst[k]);
+        else
+            qsthat[k] = o->qst[k];
+        hsthat[k] = mcp[k] * shat[k] + mrl[k] * qsthat[k];
+        if (fabs(gamma[k - 1] - gamma[k]) > 1.E-6)
+            gamhat[k] = log(gamma[k - 1] / gamma[k]) * gamma[k - 1] * gamma[k] / (gamma[k - 1] - gamma[k]);
+        else
+            gamhat[k] = gamma[k];
+    }
+
+    o->jt = (lel > P.limcnv + 1) ? lel : P.limcnv + 1;                           /* :3383-3390 */
+    o->jt = (o->jt < pver) ? o->jt : pver;
+    o->jd = pver;
+    o->jlcl = lel;
+    hmin = 1.E6;
+    o->j0 = pver;   /* not initialised by the reference; always assigned below for physical soundings */
+
+    for (int k = msg + 1; k <= pver; ++k) {                                      /* :3395-3402 */
+        if (o->hsat[k] <= hmin && k >= o->jt && k <= jb) { hmin = o->hsat[k]; o->j0 = k; }
+    }
+    o->j0 = (o->j0 < jb - 2) ? o->j0 : jb - 2;                                   /* :3404-3409 */
+    o->j0 = (o->j0 > o->jt + 2) ? o->j0 : o->jt + 2;
+    o->j0 = (o->j0 < pver) ? o->j0 : pver;
+
+    for (int k = msg + 1; k <= pver; ++k) {                                      /* :3414-3424 */
+        if (k >= o->jt && k <= jb) {
+            hu[k] = o->hmn[mx] + cp * tiedke_msk;
+            o->su[k] = s[mx] + tiedke_msk / (1.0 + cpvir * o->qu[k]);
+        }
+    }
+
+    for (int k = pver - 1; k >= msg + 1; --k) {                                  /* :3430-3442 */
+        if (k < jb && k >= o->jt) {
+            k1[k] = k1[k + 1] + (o->hmn[mx] - o->hmn[k]) * dz[k];
+            ihat[k] = 0.5 * (k1[k + 1] + k1[k]);
+            i2[k] = i2[k + 1] + ihat[k] * dz[k];
+            idag[k] = 0.5 * (i2[k + 1] + i2[k]);
+            i3[k] = i3[k + 1] + idag[k] * dz[k];
+            iprm[k] = 0.5 * (i3[k + 1] + i3[k]);
+            i4[k] = i4[k + 1] + iprm[k] * dz[k];
+        }
+    }
+
+    hmin = 1.E6;                                                                 /* :3446-3456 */
+    for (int k = msg + 1; k <= pver; ++k) {
+        if (k >= o->j0 && k <= jb && o->hmn[k] <= hmin) {
+            hmin = o->hmn[k];
+            expdif = o->hmn[mx] - hmin;
+        }
+    }
+
+    for (int k = msg + 2; k <= pver; ++k) {                                      /* :3462-3487 */
+        expnum = 0.0;
+        ftemp = 0.0;
+        if (k < o->jt || k >= jb) {
+            k1[k] = 0.0;
+            expnum = 0.0;
+        } else {
+            expnum = o->hmn[mx] - (o->hsat[k - 1] * (zf[k] - z[k]) + o->hsat[k] * (z[k - 1] - zf[k])) / (z[k - 1] - z[k]);
+        }
+        if ((expdif > 100.0 && expnum > 0.0) && k1[k] > expnum * dz[k]) {
+            ftemp = expnum / k1[k];
+            double ft2 = ftemp * ftemp, ft3 = ft2 * ftemp, ft4 = ft2 * ft2;
+            double i2sq = i2[k] * i2[k], i2cu = i2sq * i2[k];
+            double k1sq = k1[k] * k1[k], k1cu = k1sq * k1[k];
+            f[k] = ftemp + i2[k] / k1[k] * ft2 + (2.0 * i2sq - k1[k] * i3[k]) / k1sq * ft3
+                   + (-5.0 * k1[k] * i2[k] * i3[k] + 5.0 * i2cu + k1sq * i4[k]) / k1cu * ft4;
+            f[k] = fmax(f[k], 0.0);
+            f[k] = fmin(f[k], P.entrmn);
+        }
+    }
+    if (o->j0 < jb) {                                                            /* :3488-3492 */
+        if (f[o->j0] < 1.E-6 && f[o->j0 + 1] > f[o->j0]) o->j0 = o->j0 + 1;
+    }
+    for (int k = msg + 2; k <= pver; ++k) {                                      /* :3493-3499 */
+        if (k >= o->jt && k <= o->j0) f[k] = fmax(f[k], f[k - 1]);
+    }
+    eps0 = f[o->j0];                                                             /* :3500-3503 */
+    eps[jb] = eps0;
+    for (int k = pver; k >= msg + 1; --k) {                                      /* :3507-3518 */
+        if (k >= o->j0 && k <= jb) eps[k] = f[o->j0];
+    }
+    for (int k = pver; k >= msg + 1; --k) {
+        if (k < o->j0 && k >= o->jt) eps[k] = f[k];
+    }
+
+    /* iter = 1 only (itnum = 1 without microphysics) */
+    if (eps0 > 0.0) {                                                            /* :3550-3554 */
+        o->mu[jb] = 1.0;
+        o->eu[jb] = o->mu[jb] / dz[jb];
+    }
+    const int tmplel = o->jt;                                                    /* :3558 */
+    for (int k = pver; k >= msg + 1; --k) {                                      /* :3561-3571 */
+        if (eps0 > 0.0 && (k >= tmplel && k < jb)) {
+            zuef = zf[k] - zf[jb];
+            rmue = (1.0 / eps0) * (exp(eps[k + 1] * zuef) - 1.0) / zuef;
+            o->mu[k] = (1.0 / eps0) * (exp(eps[k] * zuef) - 1.0) / zuef;
+            o->eu[k] = (rmue - o->mu[k + 1]) / dz[k];
+            o->du[k] = (rmue - o->mu[k]) / dz[k];
+        }
+    }
+
+    const int khighest = lel, klowest = jb;                                      /* :3573-3578, one column */
+    for (int k = klowest - 1; k >= khighest; --k) {                              /* :3579-3598 */
+        if (k <= jb - 1 && k >= lel && eps0 > 0.0) {
+            if (o->mu[k] < 0.02) {
+                hu[k] = o->hmn[k];
+                o->mu[k] = 0.0;
+                o->eu[k] = 0.0;
+                o->du[k] = o->mu[k + 1] / dz[k];
+            } else {
+                hu[k] = o->mu[k + 1] / o->mu[k] * hu[k + 1] + dz[k] / o->mu[k] * (o->eu[k] * o->hmn[k] - o->du[k] * o->hsat[k]);
+            }
+        }
+    }
+
+    doit = 1;                                                                    /* :3603-3628 */
+    const double totfrz = 0.0;      /* frz == 0 without microphysics */
+    for (int k = klowest - 2; k >= khighest - 1; --k) {
+        if (doit && k <= jb - 2 && k >= lel - 1) {
+            if (hu[k] <= hsthat[k] && hu[k + 1] > hsthat[k + 1] && o->mu[k] >= 0.02) {
+                if (hu[k] - hsthat[k] < -2000.0) { o->jt = k + 1; doit = 0; }
+                else { o->jt = k; doit = 0; }
+            } else if ((hu[k] > hu[jb] && totfrz <= 0.0) || o->mu[k] < 0.02) {
+                o->jt = k + 1;
+                doit = 0;
+            }
+        }
+    }
+
+    for (int k = pver; k >= msg + 1; --k) {                                      /* :3632-3646 */
+        if (k >= lel && k <= o->jt && eps0 > 0.0) {
+            o->mu[k] = 0.0; o->eu[k] = 0.0; o->du[k] = 0.0; hu[k] = o->hmn[k];
+        }
+        if (k == o->jt && eps0 > 0.0) {
+            o->du[k] = o->mu[k + 1] / dz[k];
+            o->eu[k] = 0.0;
+            o->mu[k] = 0.0;
+        }
+    }
+
+    for (int k = pver; k >= msg + 2; --k) {                                      /* :3649-3654 */
+        tu[k] = (hu[k] - grav * zf[k] - (1.0 + dcol * tmelt) * rl * o->qu[k])
+                / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * o->qu[k]));
+    }
+
+    done = 0;                                                                    /* :3656-3692 */
+    for (int k = pver; k >= msg + 2; --k) {
+        if (k == jb && eps0 > 0.0) {
+            o->qu[k] = q[mx];
+            tu[k] = (hu[k] - grav * zf[k] - (1.0 + dcol * tmelt) * rl * o->qu[k])
+                    / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * o->qu[k]));
+            o->su[k] = (hu[k] - (1.0 - dcol * (tu[k] - tmelt)) * rl * o->qu[k]) / ((1.0 + cpvir * o->qu[k]) * cp);
+        }
+        if ((!done && k > o->jt && k < jb) && eps0 > 0.0) {
+            o->su[k] = o->mu[k + 1] / o->mu[k] * o->su[k + 1] + dz[k] / o->mu[k] * (o->eu[k] - o->du[k]) * s[k];
+            o->qu[k] = o->mu[k + 1] / o->mu[k] * o->qu[k + 1] + dz[k] / o->mu[k] * (o->eu[k] * q[k] - o->du[k] * o->qst[k]);
+            /* 0.85 is a default-REAL literal in the reference (:3680): single precision promoted */
+            tu[k] = o->su[k] - grav / ((1.0 + (double)0.85f * o->qu[k]) * cp) * zf[k];
+            qsat_hPa(tu[k], (p[k] + p[k - 1]) / 2.0, &estu, &qstu);
+            if (o->qu[k] >= qstu) {
+                o->jlcl = k;
+                done = 1;
+            }
+        }
+        if (done) break;                                                         /* :3690 (kount >= il2g) */
+    }
+    for (int k = msg + 2; k <= pver; ++k) {                                      /* :3693-3707 */
+        if ((k > o->jt && k <= o->jlcl) && eps0 > 0.0) {
+            o->qu[k] = qsthat[k] + gamhat[k] * (hu[k] - hsthat[k]) / ((1.0 - dcol * (tu[k] - tmelt)) * rl * (1.0 + gamhat[k]));
+            o->su[k] = shat[k] + (hu[k] - hsthat[k]) / ((1.0 + cpvir * o->qu[k]) * cp * (1.0 + gamhat[k]));
+            tu[k] = o->su[k] - grav / ((1.0 + cpvir * o->qu[k]) * cp) * zf[k];
+        }
+    }
+
+    for (int k = pver; k >= msg + 2; --k) {                                      /* :3716-3739 */
+        if (k >= o->jt && k < jb && eps0 > 0.0) {
+            o->cu[k] = ((o->mu[k] * o->su[k] - o->mu[k + 1] * o->su[k + 1]) / dz[k] - (o->eu[k] - o->du[k]) * s[k]) / (rl / cp)
+                       * ((1.0 + cpvir * o->qu[k]) / (1.0 - dcol * (tu[k] - tmelt)));
+            if (k == o->jt) o->cu[k] = 0.0;
+            o->cu[k] = fmax(0.0, o->cu[k]);
+        }
+    }
+
+    for (int k = pver; k >= msg + 2; --k) {                                      /* :3846-3870 */
+        o->rprd[k] = 0.0;
+        if (k >= o->jt && k < jb && eps0 > 0.0 && o->mu[k] >= 0.0) {
+            if (o->mu[k] > 0.0) {
+                ql1 = 1.0 / o->mu[k] * (o->mu[k + 1] * o->ql[k + 1] - dz[k] * o->du[k] * o->ql[k + 1] + dz[k] * o->cu[k]);
+                o->ql[k] = ql1 / (1.0 + dz[k] * c0mask);
+            } else {
+                o->ql[k] = 0.0;
+            }
+            totpcp = totpcp + dz[k] * (o->cu[k] - o->du[k] * o->ql[k + 1]);
+            o->rprd[k] = c0mask * o->mu[k] * o->ql[k];
+            o->qcde[k] = o->ql[k];
+        }
+    }
+
+    /* downdraft :3880-3975 */
+    alfa = P.alfadet;
+    o->jt = (o->jt < jb - 1) ? o->jt : jb - 1;
+    o->jd = (o->j0 > o->jt + 1) ? o->j0 : o->jt + 1;
+    o->jd = (o->jd < jb) ? o->jd : jb;
+    hd[o->jd] = o->hmn[o->jd - 1];
+    if (o->jd < jb && eps0 > 0.0) {
+        epsm = eps0;
+        o->md[o->jd] = -alfa * epsm / eps0;
+    }
+    for (int k = msg + 1; k <= pver; ++k) {                                      /* :3896-3904 */
+        if ((k > o->jd && k <= jb) && eps0 > 0.0) {
+            zdef = zf[o->jd] - zf[k];
+            o->md[k] = -alfa / (2.0 * eps0) * (exp(2.0 * epsm * zdef) - 1.0) / zdef;
+        }
+    }
+    for (int k = msg + 1; k <= pver; ++k) {                                      /* :3906-3913 */
+        if ((k >= o->jt && k <= jb) && eps0 > 0.0 && o->jd < jb) {
+            ratmjb = fmin(fabs(o->mu[jb] / o->md[jb]), 1.0);
+            o->md[k] = o->md[k] * ratmjb;
+        }
+    }
+    small = 1.e-20;
+    for (int k = msg + 1; k <= pver; ++k) {                                      /* :3916-3924 */
+        if ((k >= o->jt && k <= pver) && eps0 > 0.0) {
+            o->ed[k - 1] = (o->md[k - 1] - o->md[k]) / dz[k - 1];
+            mdt = fmin(o->md[k], -small);
+            hd[k] = (o->md[k - 1] * hd[k - 1] - dz[k - 1] * o->ed[k - 1] * o->hmn[k - 1]) / mdt;
+        }
+    }
+    for (int k = msg + 2; k <= pver; ++k) {                                      /* :3928-3941 */
+        if ((k >= o->jd && k <= jb) && eps0 > 0.0 && o->jd < jb) {
+            qds[k] = qsthat[k] + gamhat[k] * (hd[k] - hsthat[k]) / (rl * (1.0 + gamhat[k]));
+            td[k] = (hd[k] - grav * zf[k] - (1.0 + dcol * tmelt) * rl * qds[k])
+                    / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * qds[k]));
+            qds[k] = qsthat[k] + gamhat[k] * (hd[k] - hsthat[k]) / ((1.0 - dcol * (td[k] - tmelt)) * rl * (1.0 + gamhat[k]));
+        }
+    }
+    {                                                                            /* :3943-3951 */
+        const int k = o->jd;
+        o->qd[k] = qds[k];
+        o->sd[k] = (hd[k] - (1.0 - dcol * (td[k] - tmelt)) * rl * o->qd[k]) / ((1.0 + cpvir * o->qd[k]) * cp);
+        td[k] = o->sd[k] - grav / ((1.0 + cpvir * o->qd[k]) * cp) * zf[k];
+    }
+    for (int k = msg + 2; k <= pver; ++k) {                                      /* :3953-3971 */
+        if (k >= o->jd && k < jb && eps0 > 0.0) {
+            o->qd[k + 1] = qds[k + 1];
+            o->evp[k] = -o->ed[k] * q[k] + (o->md[k] * o->qd[k] - o->md[k + 1] * o->qd[k + 1]) / dz[k];
+            o->evp[k] = fmax(o->evp[k], 0.0);
+            mdt = fmin(o->md[k + 1], -small);
+            o->sd[k + 1] = (((1.0 - dcol * (td[k] - tmelt)) * rl / ((1.0 + cpvir * o->qd[k]) * cp) * o->evp[k] - o->ed[k] * s[k]) * dz[k]
+                            + o->md[k] * o->sd[k]) / mdt;
+            totevp = totevp - dz[k] * o->ed[k] * q[k];
+        }
+    }
+    totevp = totevp + o->md[o->jd] * o->qd[o->jd] - o->md[jb] * o->qd[jb];       /* :3974 */
+
+    totpcp = fmax(totpcp, 0.0);
+    totevp = fmax(totevp, 0.0);
+    for (int k = msg + 2; k <= pver; ++k) {                                      /* :3993-4009 */
+        if (totevp > 0.0 && totpcp > 0.0) {
+            o->md[k] = o->md[k] * fmin(1.0, totpcp / (totevp + totpcp));
+            o->ed[k] = o->ed[k] * fmin(1.0, totpcp / (totevp + totpcp));
+            o->evp[k] = o->evp[k] * fmin(1.0, totpcp / (totevp + totpcp));
+        } else {
+            o->md[k] = 0.0; o->ed[k] = 0.0; o->evp[k] = 0.0;
+        }
+        o->cmeg[k] = o->cu[k] - o->evp[k];
+        o->rprd[k] = o->rprd[k] - o->evp[k];
+    }
+    o->pflx[1] = 0.0;                                                            /* :4012-4017 */
+    for (int k = 2; k <= pver + 1; ++k) o->pflx[k] = o->pflx[k - 1] + o->rprd[k - 1] * dz[k - 1];
+    for (int k = msg + 1; k <= pver; ++k) o->mc[k] = o->mu[k] + o->md[k];
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * closure :4028-4260 (one gathered column)
+ * ---------------------------------------------------------------------------------------------- */
+static double closure(int pver, int msg, const double *q, const double *t, const double *p, const double *s,
+                      const double *tp, const double *qu, const double *su, const double *mc, const double *du,
+                      const double *mu, const double *md, const double *qd, const double *sd, const double *qhat,
+                      const double *shat, const double *dp, const double *qstp, const double *zf, const double *ql,
+                      double dsubcld, double cape, double tl, int lcl, int lel, int jt, int mx)
+{
+    double dtpdt[NL], dqsdtp[NL], dtmdt[NL], dqmdt[NL], dboydt[NL], thetavp[NL], thetavm[NL];
+    const double rd = rgas;
+    double mb = 0.0;
+    double eb = p[mx] * q[mx] / (eps1 + q[mx]);
+    double dtbdt = (1.0 / dsubcld) * (mu[mx] * (shat[mx] - su[mx]) + md[mx] * (shat[mx] - sd[mx]));
+    double dqbdt = (1.0 / dsubcld) * (mu[mx] * (qhat[mx] - qu[mx]) + md[mx] * (qhat[mx] - qd[mx]));
+    double debdt = eps1 * p[mx] / ((eps1 + q[mx]) * (eps1 + q[mx])) * dqbdt;
+    double lg = (3.5 * log(t[mx]) - log(eb) - 4.805);
+    double dtldt = -2840.0 * (3.5 / t[mx] * dtbdt - debdt / eb) / (lg * lg);
+
+    for (int k = 0; k < NL; ++k) { dtmdt[k] = 0.0; dqmdt[k] = 0.0; dboydt[k] = 0.0; }
+
+    for (int k = msg + 1; k <= pver - 1; ++k) {                                  /* :4154-4169 */
+        if (k == jt) {
+            dqmdt[k] = (1.0 / dp[k]) * (mu[k + 1] * (qu[k + 1] - qhat[k + 1] + ql[k + 1]) + md[k + 1] * (qd[k + 1] - qhat[k + 1]));
+            dtmdt[k] = (1.0 / dp[k]) * (mu[k + 1] * (su[k + 1] - shat[k + 1] - rl / cp * ql[k + 1]) + md[k + 1] * (sd[k + 1] - shat[k + 1]));
+        }
+    }
+    const double beta = 0.0;
+    for (int k = msg + 1; k <= pver - 1; ++k) {                                  /* :4172-4189 */
+        if (k > jt && k < mx) {
+            dtmdt[k] = (mc[k] * (shat[k] - s[k]) - mc[k + 1] * (shat[k + 1] - s[k])) / dp[k]
+                       - rl / cp * du[k] * (beta * ql[k] + (1 - beta) * ql[k + 1]);
+            dqmdt[k] = (mu[k + 1] * (qu[k + 1] - qhat[k + 1] + cp / rl * (su[k + 1] - s[k]))
+                        - mu[k] * (qu[k] - qhat[k] + cp / rl * (su[k] - s[k]))
+                        + md[k + 1] * (qd[k + 1] - qhat[k + 1] + cp / rl * (sd[k + 1] - s[k]))
+                        - md[k] * (qd[k] - qhat[k] + cp / rl * (sd[k] - s[k]))) / dp[k]
+                       + du[k] * (beta * ql[k] + (1 - beta) * ql[k + 1]);
+        }
+    }
+    for (int k = msg + 1; k <= pver; ++k) {                                      /* :4191-4222 */
+        if (k >= lel && k <= lcl) {
+            thetavp[k] = tp[k] * pow(1000.0 / p[k], rd / cp) * (1.0 + 1.608 * qstp[k] - q[mx]);
+            thetavm[k] = t[k] * pow(1000.0 / p[k], rd / cp) * (1.0 + 0.608 * q[k]);
+            dqsdtp[k] = qstp[k] * (1.0 + qstp[k] / eps1) * eps1 * rl / (rd * (tp[k] * tp[k]));
+            dtpdt[k] = tp[k] / (1.0 + rl / cp * (dqsdtp[k] - qstp[k] / tp[k]))
+                       * (dtbdt / t[mx] + rl / cp * (dqbdt / tl - q[mx] / (tl * tl) * dtldt));
+            dboydt[k] = ((dtpdt[k] / tp[k] + 1.0 / (1.0 + 1.608 * qstp[k] - q[mx]) * (1.608 * dqsdtp[k] * dtpdt[k] - dqbdt))
+                         - (dtmdt[k] / t[k] + 0.608 / (1.0 + 0.608 * q[k]) * dqmdt[k])) * grav * thetavp[k] / thetavm[k];
+        }
+    }
+    for (int k = msg + 1; k <= pver; ++k) {                                      /* :4224-4239 */
+        if (k > lcl && k < mx) {
+            thetavp[k] = tp[k] * pow(1000.0 / p[k], rd / cp) * (1.0 + 0.608 * q[mx]);
+            thetavm[k] = t[k] * pow(1000.0 / p[k], rd / cp) * (1.0 + 0.608 * q[k]);
+            dboydt[k] = (dtbdt / t[mx] + 0.608 / (1.0 + 0.608 * q[mx]) * dqbdt - dtmdt[k] / t[k]
+                         - 0.608 / (1.0 + 0.608 * q[k]) * dqmdt[k]) * grav * thetavp[k] / thetavm[k];
+        }
+    }
+    double dadt = 0.0;                                                           /* :4244-4257 */
+    for (int k = lel; k <= mx - 1; ++k) dadt = dadt + dboydt[k] * (zf[k] - zf[k + 1]);
+    double dltaa = -1.0 * (cape - P.capelmt);
+    if (dadt != 0.0) mb = fmax(dltaa / P.tau / dadt, 0.0);
+    return mb;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * q1q2_pjr :4262-4421 (one gathered column; ktm = jt, kbm = mx -- levels above jt evaluate to zero)
+ * ---------------------------------------------------------------------------------------------- */
+static void q1q2_pjr(int pver, int msg, const double *qu, const double *su, const double *du, const double *qhat,
+                     const double *shat, const double *dp, const double *mu, const double *md, const double *sd,
+                     const double *qd, const double *ql, double dsubcld, int jt, int mx, const double *evp,
+                     const double *cu, double *dqdt, double *dsdt, double *dl)
+{
+    for (int k = msg + 1; k <= pver; ++k) { dsdt[k] = 0.0; dqdt[k] = 0.0; dl[k] = 0.0; }
+    for (int k = jt; k <= pver - 1; ++k) {                                       /* :4364-4399 */
+        double emc = -cu[k] + evp[k];
+        dsdt[k] = -rl / cp * emc + (mu[k + 1] * (su[k + 1] - shat[k + 1]) - mu[k] * (su[k] - shat[k])
+                                    + md[k + 1] * (sd[k + 1] - shat[k + 1]) - md[k] * (sd[k] - shat[k])) / dp[k];
+        dqdt[k] = emc + (mu[k + 1] * (qu[k + 1] - qhat[k + 1]) - mu[k] * (qu[k] - qhat[k])
+                         + md[k + 1] * (qd[k + 1] - qhat[k + 1]) - md[k] * (qd[k] - qhat[k])) / dp[k];
+        dl[k] = du[k] * ql[k + 1];
+    }
+    for (int k = mx; k <= pver; ++k) {                                           /* :4402-4418 */
+        if (k == mx) {
+            dsdt[k] = (1.0 / dsubcld) * (-mu[k] * (su[k] - shat[k]) - md[k] * (sd[k] - shat[k]));
+            dqdt[k] = (1.0 / dsubcld) * (-mu[k] * (qu[k] - qhat[k]) - md[k] * (qd[k] - qhat[k]));
+        } else if (k > mx) {
+            dsdt[k] = dsdt[k - 1];
+            dqdt[k] = dqdt[k - 1];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * zm_convr :231-1709, one column.  Returns 1 if the column ends up in the gathered (deep) set.
+ * Full-layout outputs are written in place (already zero-initialised); gathered outputs go to `g`.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    double mu[NL], md[NL], du[NL], eu[NL], ed[NL], dp[NL], dsubcld;
+    int jt, maxg;
+} gath_out;
+
+static void interface_values(int pver, int msg, const double *sg, const double *qg, double *shat, double *qhat)
+{
+    for (int k = msg + 2; k <= pver; ++k) {                                      /* :1007-1027 */
+        double sdifr = 0.0, qdifr = 0.0;
+        if (sg[k] > 0.0 || sg[k - 1] > 0.0) sdifr = fabs((sg[k] - sg[k - 1]) / fmax(sg[k - 1], sg[k]));
+        if (qg[k] > 0.0 || qg[k - 1] > 0.0) qdifr = fabs((qg[k] - qg[k - 1]) / fmax(qg[k - 1], qg[k]));
+        if (sdifr > 1.E-6) shat[k] = log(sg[k - 1] / sg[k]) * sg[k - 1] * sg[k] / (sg[k - 1] - sg[k]);
+        else shat[k] = 0.5 * (sg[k] + sg[k - 1]);
+        if (qdifr > 1.E-6) qhat[k] = log(qg[k - 1] / qg[k]) * qg[k - 1] * qg[k] / (qg[k - 1] - qg[k]);
+        else qhat[k] = 0.5 * (qg[k] + qg[k - 1]);
+    }
+}
+
+typedef struct {   /* 1-based views of one column of the io struct */
+    const double *t, *qh, *pap, *dpp, *zm, *paph, *zi;
+    double geos, pblh, tpert, landfrac;
+    double *qtnd, *heat, *cme, *zdu, *rprd, *dlf, *ql, *dif, *dnlf, *dnif, *eurt, *mcon, *pflx;
+    double *prec, *jctop, *jcbot, *cape, *rliq, *rice;
+    int32_t *status;
+} col_view;
+
+static int zm_convr_column(int pver, double delt, const col_view *c, gath_out *g)
+{
+    const int msg = P.limcnv - 1;
+    double q[NL], p[NL], z[NL], s[NL], zf[NL], pf[NL], shat[NL], qhat[NL], dmpdz[NL], dp[NL];
+    double dqdt[NL], dsdt[NL], dlg[NL];
+    double zs, pblt, mb, mumax;
+    static __thread buoy_out b;      /* large; keep off the stack of the caller chain */
+    static __thread cld_out cl;
+
+    /* initialise outputs :559-563,625-650,771-784 */
+    for (int k = 1; k <= pver; ++k) {
+        c->qtnd[k] = 0.0; c->heat[k] = 0.0; c->mcon[k] = 0.0; c->pflx[k] = 0.0; c->cme[k] = 0.0; c->rprd[k] = 0.0;
+        c->zdu[k] = 0.0; c->ql[k] = 0.0; c->dlf[k] = 0.0; c->eurt[k] = 0.0; c->dif[k] = 0.0; c->dnlf[k] = 0.0;
+        c->dnif[k] = 0.0;
+    }
+    c->mcon[pver + 1] = 0.0;
+    c->pflx[pver + 1] = 0.0;
+    *c->rliq = 0.0; *c->rice = 0.0; *c->prec = 0.0;
+    *c->jctop = pver; *c->jcbot = 1;
+    *c->status = 0;
+
+    for (int k = 1; k <= pver; ++k) dmpdz[k] = -P.tentrm;                        /* :544 */
+
+    zs = c->geos * rgrav;                                                        /* :825-837 */
+    pf[pver + 1] = c->paph[pver + 1] * 0.01;
+    zf[pver + 1] = c->zi[pver + 1] + zs;
+    for (int k = 1; k <= pver; ++k) {
+        p[k] = c->pap[k] * 0.01;
+        pf[k] = c->paph[k] * 0.01;
+        z[k] = c->zm[k] + zs;
+        zf[k] = c->zi[k] + zs;
+    }
+    pblt = pver;                                                                 /* :777,839-843 */
+    for (int k = pver - 1; k >= msg + 1; --k)
+        if (fabs(z[k] - zs - c->pblh) < (zf[k] - zf[k + 1]) * 0.5) pblt = k;
+
+    for (int k = 1; k <= pver; ++k) {                                            /* :849-860 */
+        q[k] = c->qh[k];
+        s[k] = c->t[k] + (grav / ((1.0 + P.zvir * q[k]) * cpres)) * z[k];
+        shat[k] = s[k];
+        qhat[k] = q[k];
+    }
+
+    b.status = 0;
+    buoyan_dilute(pver, msg, q, c->t, p, z, pf, pblt, c->zi, zs, c->tpert, dmpdz, 0.0, &b);   /* :886 */
+    *c->cape = b.cape;
+    *c->status |= b.status ? COLPHYS_STATUS_BRENT_NOT_CONVERGED : 0;
+
+    if (!(b.cape > P.capelmt && b.cin < b.cape * P.cin_threshd)) return 0;      /* :908-917 */
+
+    /* gathered profiles are the column's own (:926-940) */
+    for (int k = 1; k <= pver; ++k) dp[k] = 0.01 * c->dpp[k];
+    int maxg = b.mx, lelg = b.lel;
+    double dsubcld = 0.0;
+    for (int k = msg + 1; k <= pver; ++k)                                        /* :995-1001 */
+        if (k >= maxg) dsubcld = dsubcld + dp[k];
+    interface_values(pver, msg, s, q, shat, qhat);
+
+    cldprp(pver, msg, q, c->t, p, z, s, zf, shat, qhat, maxg, lelg, c->landfrac, &cl);          /* :1032 */
+
+    /* second call :1046-1078: test-parcel entrainment = mean of the ensemble's eu */
+    {
+        double hk = 0.0, dmmx = 0.0, dmsm = 0.0;
+        const double orgc = 1.0;
+        for (int k = 1; k <= pver; ++k) dmpdz[k] = -1.0;
+        for (int k = pver; k >= msg + 1; --k) {
+            if (cl.eu[k] > 0) {
+                dmmx = -fmax(-dmmx, cl.eu[k]);
+                dmsm = dmsm - cl.eu[k];
+                hk = hk + 1.0;
+            }
+        }
+        if (hk > 0) {
+            dmsm = dmsm / hk;
+            for (int k = 1; k <= pver; ++k) dmpdz[k] = dmsm * orgc + dmmx * (1.0 - orgc);
+        }
+    }
+    {
+        double cin_prev = b.cin;
+        b.status = 0;
+        buoyan_dilute(pver, msg, q, c->t, p, z, pf, pblt, c->zi, zs, c->tpert, dmpdz, cin_prev, &b);   /* :1080 */
+        *c->cape = b.cape;
+        *c->status |= b.status ? COLPHYS_STATUS_BRENT_NOT_CONVERGED : 0;
+    }
+    if (!(b.cape > P.capelmt && b.cin < b.cape * P.cin_threshd)) return 0;      /* :1099-1107 retrigger */
+
+    maxg = b.mx; lelg = b.lel;                                                   /* :1156-1195 */
+    dsubcld = 0.0;
+    for (int k = msg + 1; k <= pver; ++k)
+        if (k >= maxg) dsubcld = dsubcld + dp[k];
+    interface_values(pver, msg, s, q, shat, qhat);
+
+    cldprp(pver, msg, q, c->t, p, z, s, zf, shat, qhat, maxg, lelg, c->landfrac, &cl);          /* :1216 */
+
+    for (int k = msg + 1; k <= pver; ++k) c->eurt[k] = -dmpdz[k];                /* :1233-1237 */
+
+    for (int k = msg + 1; k <= pver; ++k) {                                      /* :1252-1262 */
+        cl.du[k] = cl.du[k] * (zf[k] - zf[k + 1]) / dp[k];
+        cl.eu[k] = cl.eu[k] * (zf[k] - zf[k + 1]) / dp[k];
+        cl.ed[k] = cl.ed[k] * (zf[k] - zf[k + 1]) / dp[k];
+        cl.cu[k] = cl.cu[k] * (zf[k] - zf[k + 1]) / dp[k];
+        cl.cmeg[k] = cl.cmeg[k] * (zf[k] - zf[k + 1]) / dp[k];
+        cl.rprd[k] = cl.rprd[k] * (zf[k] - zf[k + 1]) / dp[k];
+        cl.evp[k] = cl.evp[k] * (zf[k] - zf[k + 1]) / dp[k];
+    }
+
+    mb = closure(pver, msg, q, c->t, p, s, b.tp, cl.qu, cl.su, cl.mc, cl.du, cl.mu, cl.md, cl.qd, cl.sd, qhat, shat,
+                 dp, b.qstp, zf, cl.ql, dsubcld, b.cape, b.tl, b.lcl, lelg, cl.jt, maxg);        /* :1273 */
+
+    mumax = 0;                                                                   /* :1285-1300 */
+    for (int k = msg + 2; k <= pver; ++k) mumax = fmax(mumax, cl.mu[k] / dp[k]);
+    if (mumax > 0.0) mb = fmin(mb, 0.5 / (delt * mumax));
+    else mb = 0.0;
+    if (P.no_deep_pbl) {                                                         /* :1304-1308 */
+        if (c->zm[cl.jt] < c->pblh) mb = 0;
+    }
+
+    for (int k = msg + 1; k <= pver; ++k) {                                      /* :1319-1331 */
+        cl.mu[k] = cl.mu[k] * mb; cl.md[k] = cl.md[k] * mb; cl.mc[k] = cl.mc[k] * mb; cl.du[k] = cl.du[k] * mb;
+        cl.eu[k] = cl.eu[k] * mb; cl.ed[k] = cl.ed[k] * mb; cl.cmeg[k] = cl.cmeg[k] * mb; cl.rprd[k] = cl.rprd[k] * mb;
+        cl.cu[k] = cl.cu[k] * mb; cl.evp[k] = cl.evp[k] * mb;
+        cl.pflx[k + 1] = cl.pflx[k + 1] * mb * 100.0 / grav;
+    }
+
+    q1q2_pjr(pver, msg, cl.qu, cl.su, cl.du, qhat, shat, dp, cl.mu, cl.md, cl.sd, cl.qd, cl.qcde, dsubcld, cl.jt, maxg,
+             cl.evp, cl.cu, dqdt, dsdt, dlg);                                                    /* :1388 */
+
+    for (int k = msg + 1; k <= pver; ++k) {                                      /* :1495-1511 */
+        q[k] = c->qh[k] + 2.0 * delt * dqdt[k];
+        c->qtnd[k] = dqdt[k];
+        c->cme[k] = cl.cmeg[k];
+        c->rprd[k] = cl.rprd[k];
+        c->zdu[k] = cl.du[k];
+        c->mcon[k] = cl.mc[k];
+        c->heat[k] = dsdt[k] * cpres;
+        c->dlf[k] = dlg[k];
+        c->pflx[k] = cl.pflx[k];
+        c->ql[k] = cl.ql[k];
+    }
+    *c->jctop = cl.jt;                                                           /* :1616-1620 */
+    *c->jcbot = maxg;
+    c->pflx[pver + 1] = cl.pflx[pver + 1];
+
+    for (int k = pver; k >= msg + 1; --k)                                        /* :1629-1638 */
+        *c->prec = *c->prec - c->dpp[k] * (q[k] - c->qh[k]) - c->dpp[k] * (c->dlf[k] + c->dif[k]) * 2.0 * delt;
+    *c->prec = rgrav * fmax(*c->prec, 0.0) / (2.0 * delt) / 1000.0;
+    for (int k = 1; k <= pver; ++k) {                                            /* :1642-1649 */
+        *c->rliq = *c->rliq + (c->dlf[k] + c->dif[k]) * c->dpp[k] / P.gravit;
+        *c->rice = *c->rice + c->dif[k] * c->dpp[k] / P.gravit;
+    }
+    *c->rliq = *c->rliq / 1000.0;
+    *c->rice = *c->rice / 1000.0;
+
+    for (int k = 1; k <= pver; ++k) {
+        g->mu[k] = cl.mu[k]; g->md[k] = cl.md[k]; g->du[k] = cl.du[k]; g->eu[k] = cl.eu[k]; g->ed[k] = cl.ed[k];
+        g->dp[k] = dp[k];
+    }
+    g->dsubcld = dsubcld;
+    g->jt = cl.jt;
+    g->maxg = maxg;
+    return 1;
+}
+
+void oracle_zm_convr(int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io *io)
+{
+    const int nchunks = (ncol + pcols - 1) / pcols;
+    const size_t L = (size_t)pver, LP = (size_t)pver + 1;
+    gath_out g;
+
+    /* gathered layout: zero fill (slots beyond lengath are don't-care in the reference) */
+    memset(io->mu, 0, sizeof(double) * ncol * L); memset(io->md, 0, sizeof(double) * ncol * L);
+    memset(io->du, 0, sizeof(double) * ncol * L); memset(io->eu, 0, sizeof(double) * ncol * L);
+    memset(io->ed, 0, sizeof(double) * ncol * L); memset(io->dp, 0, sizeof(double) * ncol * L);
+    memset(io->dsubcld, 0, sizeof(double) * ncol);
+    memset(io->jt, 0, sizeof(int32_t) * ncol); memset(io->maxg, 0, sizeof(int32_t) * ncol);
+    memset(io->ideep, 0, sizeof(int32_t) * ncol);
+
+    for (int ic = 0; ic < nchunks; ++ic) {
+        const int c0 = ic * pcols, nc = (ncol - c0 < pcols) ? ncol - c0 : pcols;
+        int lengath = 0;
+        for (int i = 0; i < nc; ++i) {
+            const size_t col = (size_t)(c0 + i);
+            col_view c = {
+                io->t + col * L - 1, io->qh + col * L - 1, io->pap + col * L - 1, io->dpp + col * L - 1,
+                io->zm + col * L - 1, io->paph + col * LP - 1, io->zi + col * LP - 1,
+                io->geos[col], io->pblh[col], io->tpert[col], io->landfrac[col],
+                io->qtnd + col * L - 1, io->heat + col * L - 1, io->cme + col * L - 1, io->zdu + col * L - 1,
+                io->rprd + col * L - 1, io->dlf + col * L - 1, io->ql + col * L - 1, io->dif + col * L - 1,
+                io->dnlf + col * L - 1, io->dnif + col * L - 1, io->eurt + col * L - 1, io->mcon + col * LP - 1,
+                io->pflx + col * LP - 1, io->prec + col, io->jctop + col, io->jcbot + col, io->cape + col,
+                io->rliq + col, io->rice + col, io->status + col};
+            if (zm_convr_column(pver, delt, &c, &g)) {
+                const size_t row = (size_t)(c0 + lengath);       /* ascending-order compaction :907-915 */
+                for (int k = 1; k <= pver; ++k) {
+                    io->mu[row * L + k - 1] = g.mu[k]; io->md[row * L + k - 1] = g.md[k];
+                    io->du[row * L + k - 1] = g.du[k]; io->eu[row * L + k - 1] = g.eu[k];
+                    io->ed[row * L + k - 1] = g.ed[k]; io->dp[row * L + k - 1] = g.dp[k];
+                }
+                io->dsubcld[row] = g.dsubcld;
+                io->jt[row] = g.jt;
+                io->maxg[row] = g.maxg;
+                io->ideep[row] = i + 1;
+                ++lengath;
+            }
+        }
+        io->lengath[ic] = lengath;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * zm_conv_evap :1712-1972 (old_snow path; zm_org = .false. => kemask = ke)
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_zm_conv_evap(int ncol, int pver, double deltat, const colphys_zm_conv_evap_io *io)
+{
+    const size_t L = (size_t)pver, LP = (size_t)pver + 1;
+    const double tmelt = P.tmelt, gravit = P.gravit, latice = P.latice, latvap = P.latvap;
+    for (int ic = 0; ic < ncol; ++ic) {
+        const double *t = io->t + ic * L - 1, *pmid = io->pmid + ic * L - 1, *pdel = io->pdel + ic * L - 1,
+                     *q = io->q + ic * L - 1, *prdprec = io->prdprec + ic * L - 1, *cldfrc = io->cldfrc + ic * L - 1;
+        double *tend_s = io->tend_s + ic * L - 1, *tend_s_snwprd = io->tend_s_snwprd + ic * L - 1,
+               *tend_s_snwevmlt = io->tend_s_snwevmlt + ic * L - 1, *tend_q = io->tend_q + ic * L - 1,
+               *ntprprd = io->ntprprd + ic * L - 1, *ntsnprd = io->ntsnprd + ic * L - 1,
+               *flxprec = io->flxprec + ic * LP - 1, *flxsnow = io->flxsnow + ic * LP - 1;
+        double prec = io->prec[ic] * 1000.0;                                     /* :1797 */
+        double evpvint = 0.0, evpprec, evpsnow, snowmlt, flxsntm, evplimit, work1, work2, kemask;
+        const double landfrac = io->landfrac[ic];
+
+        flxprec[1] = 0.0;
+        flxsnow[1] = 0.0;
+        for (int k = 1; k <= pver; ++k) {
+            double es, qs, fsnow_conv;
+            oracle_qsat_table(t[k], pmid[k], &es, &qs);                          /* :1804 */
+            {                                                                    /* cldfrc_fice :1809 */
+                const double tmax_fsnow = tmelt, tmin_fsnow = tmelt - 5.0;
+                if (t[k] > tmax_fsnow) fsnow_conv = 0.0;
+                else if (t[k] < tmin_fsnow) fsnow_conv = 1.0;
+                else fsnow_conv = (tmax_fsnow - t[k]) / (tmax_fsnow - tmin_fsnow);
+            }
+            if (t[k] > tmelt) {                                                  /* :1821-1828 */
+                flxsntm = 0.0;
+                snowmlt = flxsnow[k] * gravit / pdel[k];
+            } else {
+                flxsntm = flxsnow[k];
+                snowmlt = 0.0;
+            }
+            evplimit = fmax(1.0 - q[k] / (1.0 + q[k]) / qs, 0.0);                /* :1854 */
+            if (P.zm_org) kemask = P.ke * (1.0 - landfrac) + P.ke_lnd * landfrac;
+            else kemask = P.ke;
+            evpprec = kemask * (1.0 - cldfrc[k]) * evplimit * sqrt(flxprec[k]);  /* :1868 */
+            /* tht_tweaks: the supersaturation limiter is disabled (:1875-1878), evplimit carries through */
+            evplimit = fmin(evplimit, flxprec[k] * gravit / pdel[k]);            /* :1885 */
+            evplimit = fmin(evplimit, (prec - evpvint) * gravit / pdel[k]);      /* :1888 */
+            evpprec = fmin(evplimit, evpprec);
+            if (flxprec[k] > 0.0) {                                              /* :1898-1905 */
+                work1 = fmin(fmax(0.0, flxsntm / flxprec[k]), 1.0);
+                evpsnow = evpprec * work1;
+            } else {
+                evpsnow = 0.0;
+            }
+            evpvint = evpvint + evpprec * pdel[k] / gravit;
+            ntprprd[k] = prdprec[k] - evpprec;
+            if (flxprec[k] > 0.0) work1 = fmin(fmax(0.0, flxsnow[k] / flxprec[k]), 1.0);   /* :1924-1935 */
+            else work1 = 0.0;
+            work2 = fmax(fsnow_conv, work1);
+            if (snowmlt > 0.0) work2 = 0.0;
+            ntsnprd[k] = prdprec[k] * work2 - evpsnow - snowmlt;
+            tend_s_snwprd[k] = prdprec[k] * work2 * latice;
+            tend_s_snwevmlt[k] = -(evpsnow + snowmlt) * latice;
+            flxprec[k + 1] = flxprec[k] + ntprprd[k] * pdel[k] / gravit;         /* :1943-1948 */
+            flxsnow[k + 1] = flxsnow[k] + ntsnprd[k] * pdel[k] / gravit;
+            flxprec[k + 1] = fmax(flxprec[k + 1], 0.0);
+            flxsnow[k + 1] = fmax(flxsnow[k + 1], 0.0);
+            tend_s[k] = -evpprec * latvap + ntsnprd[k] * latice;                 /* :1956 */
+            tend_q[k] = evpprec;
+        }
+        io->prec[ic] = flxprec[pver + 1] / 1000.0;                               /* :1965-1966 */
+        io->snow[ic] = flxsnow[pver + 1] / 1000.0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * momtran :2315-2715 for u, v (ncnst = 2); gathered inputs in per-chunk layout
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_momtran(int ncol, int pver, int pcols, double dt, const colphys_momtran_io *io)
+{
+    const int nchunks = (ncol + pcols - 1) / pcols;
+    const size_t L = (size_t)pver;
+    const size_t F = (size_t)ncol * L;
+    const double mbsth = 1.e-15;
+
+    for (size_t i = 0; i < 2 * F; ++i) {                                         /* :2429-2433 */
+        io->pguall[i] = 0.0; io->pgdall[i] = 0.0; io->dqdt[i] = 0.0;
+        io->icwu[i] = io->winds[i]; io->icwd[i] = io->winds[i];
+    }
+    for (size_t i = 0; i < F; ++i) io->seten[i] = 0.0;
+
+    for (int ic = 0; ic < nchunks; ++ic) {
+        const int c0 = ic * pcols;
+        const int il2g = io->lengath[ic];
+        int ktm = pver, kbm = pver;                                              /* :2449-2454 */
+        for (int i = 0; i < il2g; ++i) {
+            if (io->jt[c0 + i] < ktm) ktm = io->jt[c0 + i];
+            if (io->mx[c0 + i] < kbm) kbm = io->mx[c0 + i];
+        }
+        for (int i = 0; i < il2g; ++i) {
+            const size_t row = (size_t)(c0 + i);
+            const size_t ii = (size_t)(c0 + io->ideep[row] - 1);
+            const double *mu = io->mu + row * L - 1, *md = io->md + row * L - 1, *du = io->du + row * L - 1,
+                         *eu = io->eu + row * L - 1, *ed = io->ed + row * L - 1, *dp = io->dp + row * L - 1;
+            const int mx = io->mx[row];
+            double cnst[NL], chat[NL], cond[NL], conu[NL], dcondt[NL], pgu[NL], pgd[NL], mududp, mddudp;
+            double mflux[2][NL + 1], wind0[2][NL], windf[2][NL], gseten[NL];
+
+            for (int m = 0; m < 2; ++m) {
+                for (int k = 0; k < NL; ++k) { wind0[m][k] = 0.0; windf[m][k] = 0.0; }
+                for (int k = 0; k < NL + 1; ++k) mflux[m][k] = 0.0;
+            }
+            for (int k = 0; k < NL; ++k) gseten[k] = 0.0;
+
+            for (int m = 0; m < 2; ++m) {
+                const double *qw = io->winds + m * F + ii * L - 1;
+                for (int k = 1; k <= pver; ++k) { cnst[k] = qw[k]; wind0[m][k] = cnst[k]; }   /* :2461-2466 */
+                for (int k = 1; k <= pver; ++k) {                                /* :2473-2488 */
+                    const int km1 = (k - 1 > 1) ? k - 1 : 1;
+                    chat[k] = 0.5 * (cnst[k] + cnst[km1]);
+                    conu[k] = chat[k];
+                    cond[k] = chat[k];
+                    dcondt[k] = 0.0;
+                }
+                pgu[1] = 0.0;                                                    /* :2497-2499 */
+                pgd[1] = 0.0;
+                for (int k = 2; k <= pver - 1; ++k) {                            /* :2501-2521 */
+                    const int km1 = k - 1, kp1 = k + 1;
+                    mududp = (mu[k] * (cnst[k] - cnst[km1]) / dp[km1] + mu[kp1] * (cnst[kp1] - cnst[k]) / dp[k]);
+                    pgu[k] = -P.momcu * 0.5 * mududp;
+                    mddudp = (md[k] * (cnst[k] - cnst[km1]) / dp[km1] + md[kp1] * (cnst[kp1] - cnst[k]) / dp[k]);
+                    pgd[k] = -P.momcd * 0.5 * mddudp;
+                }
+                {                                                                /* :2524-2535 */
+                    const int k = pver, km1 = pver - 1;
+                    mududp = mu[k] * (cnst[k] - cnst[km1]) / dp[km1];
+                    pgu[k] = -P.momcu * mududp;
+                    mddudp = md[k] * (cnst[k] - cnst[km1]) / dp[km1];
+                    pgd[k] = -P.momcd * mddudp;
+                }
+                {                                                                /* :2543-2558 */
+                    const int k = 2, km1 = 1, kk = pver;
+                    double mupdudp = mu[kk] + du[kk] * dp[kk];
+                    if (mupdudp > mbsth) conu[kk] = (+eu[kk] * cnst[kk] * dp[kk] + pgu[kk] * dp[kk]) / mupdudp;
+                    /* operator precedence of the reference kept as is (:2554) */
+                    if (md[k] < -mbsth) cond[k] = (-ed[km1] * cnst[km1] * dp[km1]) - pgd[km1] * dp[km1] / md[k];
+                }
+                for (int kk = pver - 1; kk >= 1; --kk) {                         /* :2563-2575 */
+                    const int kkp1 = kk + 1;
+                    double mupdudp = mu[kk] + du[kk] * dp[kk];
+                    if (mupdudp > mbsth)
+                        conu[kk] = (mu[kkp1] * conu[kkp1] + eu[kk] * cnst[kk] * dp[kk] + pgu[kk] * dp[kk]) / mupdudp;
+                }
+                for (int k = 3; k <= pver; ++k) {                                /* :2579-2589 */
+                    const int km1 = k - 1;
+                    if (md[k] < -mbsth)
+                        cond[k] = (md[km1] * cond[km1] - ed[km1] * cnst[km1] * dp[km1] - pgd[km1] * dp[km1]) / md[k];
+                }
+                for (int k = ktm; k <= pver; ++k) {                              /* :2596-2611 */
+                    const int kp1 = (k + 1 < pver) ? k + 1 : pver;
+                    dcondt[k] = +(mu[kp1] * (conu[kp1] - chat[kp1]) - mu[k] * (conu[k] - chat[k])
+                                  + md[kp1] * (cond[kp1] - chat[kp1]) - md[k] * (cond[k] - chat[k])) / dp[k];
+                }
+                for (int k = kbm; k <= pver; ++k) {                              /* :2615-2627 */
+                    if (k == mx)
+                        dcondt[k] = (1.0 / dp[k]) * (-mu[k] * (conu[k] - chat[k]) - md[k] * (cond[k] - chat[k]));
+                }
+                {                                                                /* :2632-2642 */
+                    double *dq = io->dqdt + m * F + ii * L - 1, *pu = io->pguall + m * F + ii * L - 1,
+                           *pd = io->pgdall + m * F + ii * L - 1, *iu = io->icwu + m * F + ii * L - 1,
+                           *id = io->icwd + m * F + ii * L - 1;
+                    for (int k = 1; k <= pver; ++k) {
+                        dq[k] = dcondt[k]; pu[k] = -pgu[k]; pd[k] = -pgd[k]; iu[k] = conu[k]; id[k] = cond[k];
+                    }
+                }
+                for (int k = ktm; k <= pver; ++k)                                /* :2646-2653 */
+                    mflux[m][k] = -mu[k] * (conu[k] - chat[k]) - md[k] * (cond[k] - chat[k]);
+                for (int k = ktm; k <= pver; ++k)                                /* :2658-2666 */
+                    windf[m][k] = cnst[k] - (mflux[m][k + 1] - mflux[m][k]) * dt / dp[k];
+            }
+            for (int k = ktm; k <= pver; ++k) {                                  /* :2675-2703 */
+                const int km1 = (k - 1 > 1) ? k - 1 : 1, kp1 = (k + 1 < pver) ? k + 1 : pver;
+                double utop = (wind0[0][k] + wind0[0][km1]) / 2.0, vtop = (wind0[1][k] + wind0[1][km1]) / 2.0;
+                double ubot = (wind0[0][kp1] + wind0[0][k]) / 2.0, vbot = (wind0[1][kp1] + wind0[1][k]) / 2.0;
+                double fket = utop * mflux[0][k] + vtop * mflux[1][k];
+                double fkeb = ubot * mflux[0][k + 1] + vbot * mflux[1][k + 1];
+                double ketend_cons = (fket - fkeb) / dp[k];
+                double ketend = ((windf[0][k] * windf[0][k] + windf[1][k] * windf[1][k])
+                                 - (wind0[0][k] * wind0[0][k] + wind0[1][k] * wind0[1][k])) * 0.5 / dt;
+                gseten[k] = ketend_cons - ketend;
+            }
+            {
+                double *se = io->seten + ii * L - 1;
+                for (int k = 1; k <= pver; ++k) se[k] = gseten[k];               /* :2706-2712 */
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * geopotential_t  /root/reference/physics/geopotential.F90:153-310
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspecies, const double *piln,
+                           const double *pmln, const double *pint, const double *pmid, const double *pdel,
+                           const double *rpdel, const double *t, const double *q, const double *rair, double gravit,
+                           const double *zvir, double *zi, double *zm)
+{
+    const size_t L = (size_t)pver, LP = (size_t)pver + 1, F = (size_t)ncol * L;
+    (void)pmln; (void)nq;
+    for (int ic = 0; ic < ncol; ++ic) {
+        const double *piln_c = piln + ic * LP - 1, *pint_c = pint + ic * LP - 1, *pmid_c = pmid + ic * L - 1,
+                     *pdel_c = pdel + ic * L - 1, *rpdel_c = rpdel + ic * L - 1, *t_c = t + ic * L - 1,
+                     *rair_c = rair + ic * L - 1, *zvir_c = zvir + ic * L - 1;
+        double *zi_c = zi + ic * LP - 1, *zm_c = zm + ic * L - 1;
+        zi_c[pver + 1] = 0.0;                                                    /* :207-209 */
+        for (int k = pver; k >= 1; --k) {
+            double hkl, hkk, tvfac, tv, rog = rair_c[k] / gravit;
+            const double q1 = q[ic * L + k - 1];
+            if (dycore_kind == COLPHYS_DYCORE_FV) {                              /* :222-226 / :282-286 */
+                hkl = piln_c[k + 1] - piln_c[k];
+                hkk = 1.0 - pint_c[k] * hkl * rpdel_c[k];
+            } else {                                                             /* :232-235 / :292-295 */
+                hkl = pdel_c[k] / pmid_c[k];
+                hkk = 0.5 * hkl;
+            }
+            if (dycore_kind != COLPHYS_DYCORE_SE) {
+                tvfac = 1.0 + zvir_c[k] * q1;                                    /* :241 */
+            } else {                                                             /* :255-275,301 */
+                double qfac = 1.0, sum_dry = 1.0;
+                for (int idx = 0; idx < nspecies; ++idx) qfac = qfac - q[idx * F + ic * L + k - 1];
+                qfac = 1.0 / qfac;
+                for (int idx = 0; idx < nspecies; ++idx) sum_dry = sum_dry + q[idx * F + ic * L + k - 1] * qfac;
+                sum_dry = 1.0 / sum_dry;
+                tvfac = (1.0 + (zvir_c[k] + 1.0) * q1 * qfac) * sum_dry;
+            }
+            tv = t_c[k] * tvfac;
+            zm_c[k] = zi_c[k + 1] + rog * tv * hkk;
+            zi_c[k] = zi_c[k + 1] + rog * tv * hkl;
+        }
+    }
+}

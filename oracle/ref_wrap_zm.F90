@@ -258,4 +258,24 @@ contains
     end do
   end subroutine ref_momtran
 
+  ! ---- L0 seams (oracle/stubs/l0_arithmetic.F90), exported so the C restatement can be pinned to them ----
+  subroutine ref_qsat_water(n, t, p, es, qs) bind(C, name='ref_qsat_water')
+    use wv_saturation, only: qsat_water
+    integer(c_int), value :: n
+    real(c_double), intent(in)  :: t(n), p(n)
+    real(c_double), intent(out) :: es(n), qs(n)
+    integer :: i
+    do i = 1, n
+      call qsat_water(t(i), p(i), es(i), qs(i))
+    end do
+  end subroutine ref_qsat_water
+
+  subroutine ref_qsat_table(n, t, p, es, qs) bind(C, name='ref_qsat_table')
+    use wv_saturation, only: qsat
+    integer(c_int), value :: n
+    real(c_double), intent(in)  :: t(n), p(n)
+    real(c_double), intent(out) :: es(n), qs(n)
+    call qsat(t, p, es, qs, n)
+  end subroutine ref_qsat_table
+
 end module ref_wrap_zm
