@@ -1,0 +1,708 @@
+// colphys_api.hip -- the C ABI of include/colphys.h: argument checks, device state, workspaces, and the
+// host-layout (chunk) entry points the ISO_C_BINDING shim calls.  No CPU fallback anywhere: without a HIP
+// device every compute entry point returns COLPHYS_ERR_NODEVICE.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "colphys_common.h"
+
+namespace {
+
+std::mutex g_mu;
+std::string g_err;
+bool g_init = false;
+int g_device = -1;
+ZmDev g_P;
+double *g_estbl = nullptr;          // device, [PLENEST+1], 1-based
+AeroDev g_A;
+bool g_aero_set = false;
+std::vector<void *> g_aero_bufs;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return fail(COLPHYS_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// grow-only device / pinned-host arenas
+struct Arena {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool host = false;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) { if (host) hipHostFree(p); else hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 8;
+        hipError_t e = host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return -1; }
+        cap = want;
+        return 0;
+    }
+    void release()
+    {
+        if (p) { if (host) hipHostFree(p); else hipFree(p); }
+        p = nullptr; cap = 0;
+    }
+};
+Arena g_ws_arena;        // ZmWorkspace
+Arena g_dev_arena;       // device staging for *_chunks
+Arena g_pin_arena;       // pinned host staging for *_chunks
+
+// carve helper
+struct Carver {
+    char *base; size_t off = 0;
+    explicit Carver(void *b) : base((char *)b) {}
+    template <class T> T *take(size_t n)
+    {
+        off = (off + 255) & ~size_t(255);
+        T *r = (T *)(base + off);
+        off += n * sizeof(T);
+        return r;
+    }
+};
+
+size_t zm_ws_bytes(int ncol, int pver)
+{
+    return 256 * 20 + sizeof(int) * (size_t)ncol * 6 + sizeof(double) * (size_t)ncol * 3 + sizeof(double) * (size_t)ncol * pver * 6 + 4096;
+}
+ZmWorkspace zm_ws_carve(void *base, int ncol, int pver)
+{
+    Carver c(base);
+    ZmWorkspace w;
+    w.count = c.take<int>(64);
+    w.list = c.take<int>(ncol);
+    w.cape1 = c.take<double>(ncol); w.cin1 = c.take<double>(ncol);
+    w.lel1 = c.take<int>(ncol); w.mx1 = c.take<int>(ncol); w.deep = c.take<int>(ncol);
+    w.jt_f = c.take<int>(ncol); w.maxg_f = c.take<int>(ncol); w.dsub_f = c.take<double>(ncol);
+    const size_t n = (size_t)ncol * pver;
+    w.mu_f = c.take<double>(n); w.md_f = c.take<double>(n); w.du_f = c.take<double>(n);
+    w.eu_f = c.take<double>(n); w.ed_f = c.take<double>(n); w.dp_f = c.take<double>(n);
+    return w;
+}
+
+// ---- profiling with HIP events on the launch stream ---------------------------------------------------
+bool g_prof = false;
+struct Pending { int kernel; hipEvent_t a, b; };
+std::vector<Pending> g_pending;
+std::vector<hipEvent_t> g_evpool;
+double g_ms[COLPHYS_K_COUNT];
+int64_t g_n[COLPHYS_K_COUNT];
+
+hipEvent_t ev_get()
+{
+    if (!g_evpool.empty()) { hipEvent_t e = g_evpool.back(); g_evpool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+void prof_drain()
+{
+    for (auto &p : g_pending) {
+        float ms = 0.f;
+        hipEventSynchronize(p.b);
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { g_ms[p.kernel] += ms; g_n[p.kernel] += 1; }
+        g_evpool.push_back(p.a);
+        g_evpool.push_back(p.b);
+    }
+    g_pending.clear();
+}
+struct ProfScope {
+    int kernel; hipStream_t st; hipEvent_t a{}, b{}; bool on;
+    ProfScope(int k, hipStream_t s) : kernel(k), st(s), on(g_prof)
+    {
+        if (on) { a = ev_get(); b = ev_get(); hipEventRecord(a, st); }
+    }
+    ~ProfScope()
+    {
+        if (on) { hipEventRecord(b, st); g_pending.push_back({kernel, a, b}); }
+    }
+};
+
+int check_ready()
+{
+    if (!g_init) return fail(COLPHYS_ERR_NOTINIT, "colphys_init has not been called");
+    return COLPHYS_OK;
+}
+int check_dims(int ncol, int pver)
+{
+    if (ncol <= 0) return fail(COLPHYS_ERR_ARG, "ncol must be > 0");
+    if (pver < 4 || pver > COLPHYS_MAX_PVER) return fail(COLPHYS_ERR_ARG, "pver out of range [4, COLPHYS_MAX_PVER]");
+    return COLPHYS_OK;
+}
+
+// host restatement of the table construction (spec: oracle/stubs/l0_arithmetic.F90), pow() as the Fortran `**`
+double h_svp_water(double t)
+{
+    const double tboil = 373.16;
+    return std::pow(10.0, -7.90298 * (tboil / t - 1.0) + 5.02808 * std::log10(tboil / t)
+                              - 1.3816e-7 * (std::pow(10.0, 11.344 * (1.0 - t / tboil)) - 1.0)
+                              + 8.1328e-3 * (std::pow(10.0, -3.49149 * (tboil / t - 1.0)) - 1.0)
+                              + std::log10(1013.246)) * 100.0;
+}
+double h_svp_ice(double t)
+{
+    const double h2otrip = 273.16;
+    return std::pow(10.0, -9.09718 * (h2otrip / t - 1.0) - 3.56654 * std::log10(h2otrip / t)
+                              + 0.876793 * (1.0 - t / h2otrip) + std::log10(6.1071)) * 100.0;
+}
+double h_svp_trans(double t, double tmelt)
+{
+    const double ttrice = 20.0;
+    double es = 0.0;
+    if (t >= (tmelt - ttrice)) es = h_svp_water(t);
+    if (t < tmelt) {
+        const double esice = h_svp_ice(t);
+        const double weight = ((tmelt - t) > ttrice) ? 1.0 : (tmelt - t) / ttrice;
+        es = weight * esice + (1.0 - weight) * es;
+    }
+    return es;
+}
+
+}  // namespace
+
+extern "C" {
+
+int colphys_abi_version(void) { return COLPHYS_ABI_VERSION; }
+const char *colphys_last_error(void) { return g_err.c_str(); }
+
+int colphys_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void colphys_zm_params_defaults(colphys_zm_params *p)
+{
+    p->tiedke_lnd = 1.0; p->entrmn = 2e-4; p->alfadet = 0.1; p->plclmin = 6.e2; p->cin_threshd = 0.33;
+    p->parcel_hscale = 0.5; p->tentrm = -p->dmpdz_param; p->cam3 = 0; p->reserved = 0;
+}
+
+int colphys_init(int device, const colphys_zm_params *p)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!p) return fail(COLPHYS_ERR_ARG, "null params");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(COLPHYS_ERR_NODEVICE, "no HIP device (the engine has no CPU path)");
+    if (device < 0 || device >= n) return fail(COLPHYS_ERR_ARG, "device index out of range");
+    if (p->zmconv_microp) return fail(COLPHYS_ERR_UNSUPPORTED, "zmconv_microp=.true. (zm_mphy) is outside the hot-path scope");
+    if (p->zm_org) return fail(COLPHYS_ERR_UNSUPPORTED, "zmconv_org=.true. is outside the hot-path scope");
+    if (p->cam3) return fail(COLPHYS_ERR_UNSUPPORTED, "cam3 non-dilute buoyan is outside the hot-path scope");
+    if (p->num_cin < 1 || p->num_cin > 5) return fail(COLPHYS_ERR_ARG, "NUM_CIN must be in 1..5 (zm_conv.F90:200)");
+    if (p->limcnv < 1) return fail(COLPHYS_ERR_ARG, "limcnv must be >= 1");
+    HIPCHK(hipSetDevice(device));
+    g_device = device;
+
+    ZmDev &P = g_P;
+    P.cpair = p->cpair; P.epsilo = p->epsilo; P.gravit = p->gravit; P.latice = p->latice; P.latvap = p->latvap;
+    P.tmelt = p->tmelt; P.rair = p->rair; P.cpwv = p->cpwv; P.cpliq = p->cpliq; P.rh2o = p->rh2o; P.cpvir = p->cpvir;
+    P.zvir = p->zvir;
+    P.c0_lnd = p->c0_lnd; P.c0_ocn = p->c0_ocn; P.ke = p->ke; P.ke_lnd = p->ke_lnd; P.momcu = p->momcu; P.momcd = p->momcd;
+    P.tiedke_add = p->tiedke_add; P.capelmt = p->capelmt; P.tau = p->tau;
+    P.tiedke_lnd = p->tiedke_lnd; P.entrmn = p->entrmn; P.alfadet = p->alfadet; P.tentrm = p->tentrm;
+    P.plclmin = p->plclmin; P.cin_threshd = p->cin_threshd; P.parcel_hscale = p->parcel_hscale;
+    // zm_convi :145-155
+    P.tfreez = p->tmelt; P.eps1 = p->epsilo; P.rl = p->latvap; P.cpres = p->cpair; P.rgrav = 1.0 / p->gravit;
+    P.rgas = p->rair; P.grav = p->gravit; P.cp = P.cpres; P.dcol = (p->cpliq - p->cpwv) / p->latvap;
+    P.omeps = 1.0 - p->epsilo;
+    P.limcnv = p->limcnv; P.num_cin = p->num_cin; P.zm_org = p->zm_org; P.no_deep_pbl = p->no_deep_pbl;
+    P.lparcel_pbl = p->lparcel_pbl;
+
+    std::vector<double> tbl(COLPHYS_PLENEST + 1, 0.0);
+    for (int i = 1; i <= COLPHYS_PLENEST; ++i) tbl[i] = h_svp_trans(COLPHYS_TMIN_TBL + (double)(i - 1), p->tmelt);
+    if (!g_estbl) HIPCHK(hipMalloc((void **)&g_estbl, sizeof(double) * (COLPHYS_PLENEST + 1)));
+    HIPCHK(hipMemcpy(g_estbl, tbl.data(), sizeof(double) * (COLPHYS_PLENEST + 1), hipMemcpyHostToDevice));
+    g_pin_arena.host = true;
+    g_init = true;
+    return COLPHYS_OK;
+}
+
+int colphys_finalize(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_init) {
+        hipDeviceSynchronize();
+        prof_drain();
+        for (auto e : g_evpool) hipEventDestroy(e);
+        g_evpool.clear();
+        if (g_estbl) hipFree(g_estbl);
+        g_estbl = nullptr;
+        for (void *b : g_aero_bufs) hipFree(b);
+        g_aero_bufs.clear();
+        g_aero_set = false;
+        g_ws_arena.release(); g_dev_arena.release(); g_pin_arena.release();
+    }
+    g_init = false;
+    return COLPHYS_OK;
+}
+
+int colphys_profile_enable(int on)
+{
+    g_prof = on != 0;
+    return COLPHYS_OK;
+}
+int colphys_profile_reset(void)
+{
+    if (g_init) { hipDeviceSynchronize(); prof_drain(); }
+    for (int i = 0; i < COLPHYS_K_COUNT; ++i) { g_ms[i] = 0.0; g_n[i] = 0; }
+    return COLPHYS_OK;
+}
+int colphys_profile_get(int kernel, double *avg_ms, int64_t *launches)
+{
+    if (kernel < 0 || kernel >= COLPHYS_K_COUNT) return fail(COLPHYS_ERR_ARG, "bad kernel id");
+    prof_drain();
+    if (avg_ms) *avg_ms = g_n[kernel] ? g_ms[kernel] / (double)g_n[kernel] : 0.0;
+    if (launches) *launches = g_n[kernel];
+    return COLPHYS_OK;
+}
+
+// =======================================================================================================
+// device-resident entry points
+// =======================================================================================================
+int colphys_geopotential_t_dev(int ncol, int pver, int dycore_kind, int nq, int nspecies, const double *piln,
+                               const double *pmln, const double *pint, const double *pmid, const double *pdel,
+                               const double *rpdel, const double *t, const double *q, const double *rair, double gravit,
+                               const double *zvir, double *zi, double *zm, void *stream)
+{
+    (void)pmln;
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    if (dycore_kind < 0 || dycore_kind > 2) return fail(COLPHYS_ERR_ARG, "bad dycore_kind");
+    if (nq < 1 || nspecies < 1 || nspecies > nq) return fail(COLPHYS_ERR_ARG, "need 1 <= nspecies <= nq");
+    if (!t || !q || !rair || !zvir || !zi || !zm) return fail(COLPHYS_ERR_ARG, "null pointer");
+    if (dycore_kind == COLPHYS_DYCORE_FV ? (!piln || !pint || !rpdel) : (!pdel || !pmid))
+        return fail(COLPHYS_ERR_ARG, "null pressure field for this dycore_kind");
+    ProfScope ps(COLPHYS_K_GEOPOTENTIAL, (hipStream_t)stream);
+    rc = launch_geopotential_t(ncol, pver, dycore_kind, nq, nspecies, piln, pint, pmid, pdel, rpdel, t, q, rair, gravit,
+                               zvir, zi, zm, (hipStream_t)stream);
+    return rc ? fail(rc, "geopotential_t launch failed") : COLPHYS_OK;
+}
+
+int colphys_zm_convr_dev(int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io *io, void *stream)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    if (!io) return fail(COLPHYS_ERR_ARG, "null io");
+    if (pcols < 1 || pcols > 1024) return fail(COLPHYS_ERR_ARG, "pcols must be in 1..1024");
+    if (g_P.limcnv + 1 > pver) return fail(COLPHYS_ERR_ARG, "limcnv must be < pver");
+    const void *ptrs[] = {io->t, io->qh, io->pap, io->dpp, io->zm, io->paph, io->zi, io->geos, io->pblh, io->tpert,
+                          io->landfrac, io->qtnd, io->heat, io->cme, io->zdu, io->rprd, io->dlf, io->ql, io->dif, io->dnlf,
+                          io->dnif, io->eurt, io->mcon, io->pflx, io->prec, io->jctop, io->jcbot, io->cape, io->rliq,
+                          io->rice, io->mu, io->md, io->du, io->eu, io->ed, io->dp, io->dsubcld, io->jt, io->maxg,
+                          io->ideep, io->lengath, io->status};
+    for (const void *p : ptrs)
+        if (!p) return fail(COLPHYS_ERR_ARG, "null pointer in colphys_zm_convr_io");
+    hipStream_t st = (hipStream_t)stream;
+    ZmWorkspace ws;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_ws_arena.reserve(zm_ws_bytes(ncol, pver))) return fail(COLPHYS_ERR_HIP, "workspace allocation failed");
+        ws = zm_ws_carve(g_ws_arena.p, ncol, pver);
+    }
+    hipEvent_t ev[4];
+    if (g_prof) for (auto &e : ev) e = ev_get();
+    rc = launch_zm_convr(g_P, ncol, pver, pcols, delt, *io, ws, st, g_prof ? ev : nullptr);
+    if (g_prof) {
+        g_pending.push_back({COLPHYS_K_ZM_TRIGGER, ev[0], ev[1]});
+        g_pending.push_back({COLPHYS_K_ZM_PLUME, ev[2], ev[3]});
+    }
+    return rc ? fail(rc, "zm_convr launch failed") : COLPHYS_OK;
+}
+
+int colphys_zm_conv_evap_dev(int ncol, int pver, double deltat, const colphys_zm_conv_evap_io *io, void *stream)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    if (!io) return fail(COLPHYS_ERR_ARG, "null io");
+    const void *ptrs[] = {io->t, io->pmid, io->pdel, io->q, io->prdprec, io->cldfrc, io->landfrac, io->prec, io->tend_s,
+                          io->tend_s_snwprd, io->tend_s_snwevmlt, io->tend_q, io->ntprprd, io->ntsnprd, io->flxprec,
+                          io->flxsnow, io->snow};
+    for (const void *p : ptrs)
+        if (!p) return fail(COLPHYS_ERR_ARG, "null pointer in colphys_zm_conv_evap_io");
+    ProfScope ps(COLPHYS_K_ZM_EVAP, (hipStream_t)stream);
+    rc = launch_zm_conv_evap(g_P, g_estbl, ncol, pver, deltat, *io, (hipStream_t)stream);
+    return rc ? fail(rc, "zm_conv_evap launch failed") : COLPHYS_OK;
+}
+
+int colphys_momtran_dev(int ncol, int pver, int pcols, double dt, const colphys_momtran_io *io, void *stream)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    if (!io) return fail(COLPHYS_ERR_ARG, "null io");
+    if (pcols < 1 || pcols > 1024) return fail(COLPHYS_ERR_ARG, "pcols must be in 1..1024");
+    const void *ptrs[] = {io->winds, io->mu, io->md, io->du, io->eu, io->ed, io->dp, io->dsubcld, io->jt, io->mx, io->ideep,
+                          io->lengath, io->dqdt, io->pguall, io->pgdall, io->icwu, io->icwd, io->seten};
+    for (const void *p : ptrs)
+        if (!p) return fail(COLPHYS_ERR_ARG, "null pointer in colphys_momtran_io");
+    ProfScope ps(COLPHYS_K_MOMTRAN, (hipStream_t)stream);
+    rc = launch_momtran(g_P, ncol, pver, pcols, dt, *io, (hipStream_t)stream);
+    return rc ? fail(rc, "momtran launch failed") : COLPHYS_OK;
+}
+
+// ---- aerosol tables -------------------------------------------------------------------------------------
+int colphys_aero_tables_set(const colphys_aero_tables *tb)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc;
+    if ((rc = check_ready())) return rc;
+    if (!tb) return fail(COLPHYS_ERR_ARG, "null tables");
+    if (tb->nmodes < 1 || tb->nspec_max < 1 || tb->nspec_max > 8) return fail(COLPHYS_ERR_UNSUPPORTED, "need 1 <= nspec_max <= 8");
+    for (void *b : g_aero_bufs) hipFree(b);
+    g_aero_bufs.clear();
+    auto up = [&](const void *src, size_t bytes, const void **dst) -> int {
+        void *d = nullptr;
+        if (!src) return -1;
+        if (hipMalloc(&d, bytes) != hipSuccess) return -1;
+        g_aero_bufs.push_back(d);
+        if (hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return -1;
+        *dst = d;
+        return 0;
+    };
+    AeroDev &A = g_A;
+    A.nmodes = tb->nmodes; A.nspec_max = tb->nspec_max; A.nswbands = tb->nswbands; A.nlwbands = tb->nlwbands;
+    A.top_lev = tb->top_lev; A.rhoh2o = tb->rhoh2o; A.rga = tb->rga; A.rair = tb->rair; A.xrmin = tb->xrmin; A.xrmax = tb->xrmax;
+    const size_t nm = tb->nmodes, ns = tb->nspec_max, nsw = tb->nswbands, nlw = tb->nlwbands;
+    const size_t tblsz = (size_t)COLPHYS_PREFI * COLPHYS_PREFR * COLPHYS_NCOEF;
+    int bad = 0;
+    bad |= up(tb->nspec, sizeof(int32_t) * nm, (const void **)&A.nspec);
+    bad |= up(tb->spectype, sizeof(int32_t) * nm * ns, (const void **)&A.spectype);
+    bad |= up(tb->sigmag, 8 * nm, (const void **)&A.sigmag);
+    bad |= up(tb->specdens, 8 * nm * ns, (const void **)&A.specdens);
+    bad |= up(tb->hygro, 8 * nm * ns, (const void **)&A.hygro);
+    bad |= up(tb->specrefindex_sw, 8 * nm * ns * nsw * 2, (const void **)&A.specrefindex_sw);
+    bad |= up(tb->specrefindex_lw, 8 * nm * ns * nlw * 2, (const void **)&A.specrefindex_lw);
+    bad |= up(tb->refrtabsw, 8 * nm * nsw * COLPHYS_PREFR, (const void **)&A.refrtabsw);
+    bad |= up(tb->refitabsw, 8 * nm * nsw * COLPHYS_PREFI, (const void **)&A.refitabsw);
+    bad |= up(tb->refrtablw, 8 * nm * nlw * COLPHYS_PREFR, (const void **)&A.refrtablw);
+    bad |= up(tb->refitablw, 8 * nm * nlw * COLPHYS_PREFI, (const void **)&A.refitablw);
+    bad |= up(tb->extpsw, 8 * nm * nsw * tblsz, (const void **)&A.extpsw);
+    bad |= up(tb->abspsw, 8 * nm * nsw * tblsz, (const void **)&A.abspsw);
+    bad |= up(tb->asmpsw, 8 * nm * nsw * tblsz, (const void **)&A.asmpsw);
+    bad |= up(tb->absplw, 8 * nm * nlw * tblsz, (const void **)&A.absplw);
+    bad |= up(tb->crefwsw, 8 * nsw * 2, (const void **)&A.crefwsw);
+    bad |= up(tb->crefwlw, 8 * nlw * 2, (const void **)&A.crefwlw);
+    if (bad) return fail(COLPHYS_ERR_HIP, "uploading aerosol tables failed (null table or hipMalloc)");
+    g_aero_set = true;
+    return COLPHYS_OK;
+}
+
+static int aero_dev(bool sw, int ncol, int pver, const colphys_modal_aero_io *io, void *stream)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    if (!g_aero_set) return fail(COLPHYS_ERR_NOTINIT, "colphys_aero_tables_set has not been called");
+    if (!io || !io->pdeldry || !io->specmmr || !io->dgnumwet || !io->qaerwat || !io->tauxar || !io->status)
+        return fail(COLPHYS_ERR_ARG, "null pointer in colphys_modal_aero_io");
+    if (sw && (!io->wa || !io->ga || !io->fa)) return fail(COLPHYS_ERR_ARG, "SW needs wa, ga, fa");
+    ProfScope ps(sw ? COLPHYS_K_AERO_SW : COLPHYS_K_AERO_LW, (hipStream_t)stream);
+    rc = sw ? launch_modal_aero_sw(g_A, ncol, pver, *io, (hipStream_t)stream)
+            : launch_modal_aero_lw(g_A, ncol, pver, *io, (hipStream_t)stream);
+    return rc ? fail(rc, "modal_aero launch failed") : COLPHYS_OK;
+}
+int colphys_modal_aero_sw_dev(int ncol, int pver, const colphys_modal_aero_io *io, void *stream) { return aero_dev(true, ncol, pver, io, stream); }
+int colphys_modal_aero_lw_dev(int ncol, int pver, const colphys_modal_aero_io *io, void *stream) { return aero_dev(false, ncol, pver, io, stream); }
+
+// =======================================================================================================
+// host-layout (chunk) entry points: Fortran (pcols, nlev, nchunks) <-> device [col][nlev]
+//   device column index = chunk*pcols + i; padding columns i >= ncol(chunk) are filled with a copy of the
+//   chunk's first column (CAM leaves +inf there) and their results are discarded.
+// =======================================================================================================
+}  // extern "C"
+
+namespace {
+
+struct Stager {
+    int nchunks, pcols;
+    const int32_t *ncol;
+    int ncd;                       // device columns = nchunks*pcols
+    Carver hc, dc;
+    hipStream_t st = nullptr;
+    Stager(int nch, int pc, const int32_t *nc, void *hbase, void *dbase) : nchunks(nch), pcols(pc), ncol(nc), ncd(nch * pc), hc(hbase), dc(dbase) {}
+
+    // pack a (pcols, nlev, nchunks) Fortran field and start its upload; returns the device pointer
+    double *in(const double *src, int nlev)
+    {
+        const size_t n = (size_t)ncd * nlev;
+        double *h = hc.take<double>(n), *d = dc.take<double>(n);
+        for (int c = 0; c < nchunks; ++c) {
+            const double *s = src + (size_t)c * pcols * nlev;
+            for (int i = 0; i < pcols; ++i) {
+                const int isrc = (i < ncol[c]) ? i : 0;
+                double *o = h + ((size_t)c * pcols + i) * nlev;
+                for (int k = 0; k < nlev; ++k) o[k] = s[(size_t)k * pcols + isrc];
+            }
+        }
+        hipMemcpyAsync(d, h, n * sizeof(double), hipMemcpyHostToDevice, st);
+        return d;
+    }
+    // nf fields, source field-major (pcols, nlev, nchunks, nf) -> device [nf][ncd][nlev], contiguous
+    double *in_multi(const double *src, int nlev, int nf)
+    {
+        const size_t n = (size_t)ncd * nlev;
+        double *h = hc.take<double>(n * nf), *d = dc.take<double>(n * nf);
+        for (int f = 0; f < nf; ++f)
+            for (int c = 0; c < nchunks; ++c) {
+                const double *s = src + (size_t)f * n + (size_t)c * pcols * nlev;
+                for (int i = 0; i < pcols; ++i) {
+                    const int isrc = (i < ncol[c]) ? i : 0;
+                    double *o = h + (size_t)f * n + ((size_t)c * pcols + i) * nlev;
+                    for (int k = 0; k < nlev; ++k) o[k] = s[(size_t)k * pcols + isrc];
+                }
+            }
+        hipMemcpyAsync(d, h, n * nf * sizeof(double), hipMemcpyHostToDevice, st);
+        return d;
+    }
+    int32_t *in_i(const int32_t *src, int nlev)
+    {
+        const size_t n = (size_t)ncd * nlev;
+        int32_t *h = hc.take<int32_t>(n), *d = dc.take<int32_t>(n);
+        for (int c = 0; c < nchunks; ++c)
+            for (int i = 0; i < pcols; ++i)
+                for (int k = 0; k < nlev; ++k) h[((size_t)c * pcols + i) * nlev + k] = src[(size_t)c * pcols * nlev + (size_t)k * pcols + i];
+        hipMemcpyAsync(d, h, n * sizeof(int32_t), hipMemcpyHostToDevice, st);
+        return d;
+    }
+    template <class T> T *out(int nlev) { return dc.take<T>((size_t)ncd * nlev); }
+
+    // download a device [col][nlev] field and scatter the first `valid(c)` columns of each chunk
+    template <class T> void back(T *dst, const T *dev, int nlev, bool gathered, const int32_t *lengath)
+    {
+        const size_t n = (size_t)ncd * nlev;
+        T *h = hc.take<T>(n);
+        hipMemcpyAsync(h, dev, n * sizeof(T), hipMemcpyDeviceToHost, st);
+        hipStreamSynchronize(st);
+        for (int c = 0; c < nchunks; ++c) {
+            const int nv = gathered ? lengath[c] : ncol[c];
+            T *o = dst + (size_t)c * pcols * nlev;
+            for (int i = 0; i < nv; ++i) {
+                const T *s = h + ((size_t)c * pcols + i) * nlev;
+                for (int k = 0; k < nlev; ++k) o[(size_t)k * pcols + i] = s[k];
+            }
+        }
+    }
+};
+
+int stage_reserve(size_t host_bytes, size_t dev_bytes)
+{
+    if (g_pin_arena.reserve(host_bytes) || g_dev_arena.reserve(dev_bytes)) return fail(COLPHYS_ERR_HIP, "staging allocation failed");
+    return COLPHYS_OK;
+}
+int check_chunks(int nchunks, int pcols, const int32_t *ncol)
+{
+    if (nchunks < 1 || pcols < 1 || !ncol) return fail(COLPHYS_ERR_ARG, "bad chunk description");
+    for (int c = 0; c < nchunks; ++c)
+        if (ncol[c] < 1 || ncol[c] > pcols) return fail(COLPHYS_ERR_ARG, "ncol(chunk) must be in 1..pcols");
+    return COLPHYS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int colphys_geopotential_t_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, int dycore_kind, int nq,
+                                  int nspecies, const double *piln, const double *pmln, const double *pint,
+                                  const double *pmid, const double *pdel, const double *rpdel, const double *t,
+                                  const double *q, const double *rair, double gravit, const double *zvir, double *zi,
+                                  double *zm)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t ncd = (size_t)nchunks * pcols, pverp = pver + 1;
+    const size_t bytes = 8 * ncd * (4 * pverp + (8 + (size_t)nq) * pver) + 64 * 256;
+    if ((rc = stage_reserve(bytes, bytes))) return rc;
+    Stager s(nchunks, pcols, ncol, g_pin_arena.p, g_dev_arena.p);
+    const bool fv = dycore_kind == COLPHYS_DYCORE_FV;
+    double *d_piln = fv ? s.in(piln, pverp) : nullptr, *d_pint = fv ? s.in(pint, pverp) : nullptr;
+    double *d_rpdel = fv ? s.in(rpdel, pver) : nullptr;
+    double *d_pmid = fv ? nullptr : s.in(pmid, pver), *d_pdel = fv ? nullptr : s.in(pdel, pver);
+    double *d_t = s.in(t, pver), *d_rair = s.in(rair, pver), *d_zvir = s.in(zvir, pver);
+    // q: (pcols,pver,nq) per chunk in CAM; here the shim passes species-major (pcols,pver,nchunks,nq)
+    double *d_q = s.in_multi(q, pver, nq);
+    double *d_zi = s.out<double>(pverp), *d_zm = s.out<double>(pver);
+    rc = colphys_geopotential_t_dev((int)ncd, pver, dycore_kind, nq, nspecies, d_piln, nullptr, d_pint, d_pmid, d_pdel,
+                                    d_rpdel, d_t, d_q, d_rair, gravit, d_zvir, d_zi, d_zm, nullptr);
+    if (rc) return rc;
+    s.back(zi, d_zi, pverp, false, nullptr);
+    s.back(zm, d_zm, pver, false, nullptr);
+    (void)pmln;
+    return COLPHYS_OK;
+}
+
+int colphys_zm_convr_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, double delt, const colphys_zm_convr_io *io)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
+    if (!io) return fail(COLPHYS_ERR_ARG, "null io");
+    std::unique_lock<std::mutex> lk(g_mu);
+    const size_t ncd = (size_t)nchunks * pcols, pverp = pver + 1;
+    const size_t bytes = 8 * ncd * (4 * pverp + 22 * (size_t)pver + 16) + 4 * ncd * 8 + 128 * 256;
+    if ((rc = stage_reserve(bytes, bytes))) return rc;
+    Stager s(nchunks, pcols, ncol, g_pin_arena.p, g_dev_arena.p);
+    colphys_zm_convr_io d = *io;
+    d.t = s.in(io->t, pver); d.qh = s.in(io->qh, pver); d.pap = s.in(io->pap, pver); d.dpp = s.in(io->dpp, pver);
+    d.zm = s.in(io->zm, pver); d.paph = s.in(io->paph, pverp); d.zi = s.in(io->zi, pverp);
+    d.geos = s.in(io->geos, 1); d.pblh = s.in(io->pblh, 1); d.tpert = s.in(io->tpert, 1); d.landfrac = s.in(io->landfrac, 1);
+    double **mid_d[] = {&d.qtnd, &d.heat, &d.cme, &d.zdu, &d.rprd, &d.dlf, &d.ql, &d.dif, &d.dnlf, &d.dnif, &d.eurt,
+                        &d.mu, &d.md, &d.du, &d.eu, &d.ed, &d.dp};
+    for (auto pp : mid_d) *pp = s.out<double>(pver);
+    d.mcon = s.out<double>(pverp); d.pflx = s.out<double>(pverp);
+    double **col_d[] = {&d.prec, &d.jctop, &d.jcbot, &d.cape, &d.rliq, &d.rice, &d.dsubcld};
+    for (auto pp : col_d) *pp = s.out<double>(1);
+    d.jt = s.out<int32_t>(1); d.maxg = s.out<int32_t>(1); d.ideep = s.out<int32_t>(1); d.status = s.out<int32_t>(1);
+    d.lengath = s.dc.take<int32_t>(nchunks);
+    lk.unlock();
+    rc = colphys_zm_convr_dev((int)ncd, pver, pcols, delt, &d, nullptr);
+    lk.lock();
+    if (rc) return rc;
+    // padding columns must not appear in the gathered set: they are copies of column 1 of their chunk, so
+    // they trigger exactly when it does; drop them on the host from ideep (ascending order is preserved)
+    std::vector<int32_t> h_len(nchunks), h_ideep(ncd), h_jt(ncd), h_maxg(ncd);
+    std::vector<double> h_dsub(ncd);
+    HIPCHK(hipMemcpy(h_len.data(), d.lengath, 4 * (size_t)nchunks, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h_ideep.data(), d.ideep, 4 * ncd, hipMemcpyDeviceToHost));
+    for (int c = 0; c < nchunks; ++c) {
+        int n = 0;
+        for (int j = 0; j < h_len[c]; ++j)
+            if (h_ideep[(size_t)c * pcols + j] <= ncol[c]) ++n;     // padding has i > ncol, and sits at the tail
+        io->lengath[c] = n;
+    }
+    const double *mid_s[] = {d.qtnd, d.heat, d.cme, d.zdu, d.rprd, d.dlf, d.ql, d.dif, d.dnlf, d.dnif, d.eurt};
+    double *mid_h[] = {io->qtnd, io->heat, io->cme, io->zdu, io->rprd, io->dlf, io->ql, io->dif, io->dnlf, io->dnif, io->eurt};
+    for (int f = 0; f < 11; ++f) s.back(mid_h[f], mid_s[f], pver, false, nullptr);
+    s.back(io->mcon, d.mcon, pverp, false, nullptr);
+    s.back(io->pflx, d.pflx, pverp, false, nullptr);
+    const double *col_s[] = {d.prec, d.jctop, d.jcbot, d.cape, d.rliq, d.rice};
+    double *col_h[] = {io->prec, io->jctop, io->jcbot, io->cape, io->rliq, io->rice};
+    for (int f = 0; f < 6; ++f) s.back(col_h[f], col_s[f], 1, false, nullptr);
+    s.back(io->status, (const int32_t *)d.status, 1, false, nullptr);
+    const double *g_s[] = {d.mu, d.md, d.du, d.eu, d.ed, d.dp};
+    double *g_h[] = {io->mu, io->md, io->du, io->eu, io->ed, io->dp};
+    for (int f = 0; f < 6; ++f) s.back(g_h[f], g_s[f], pver, true, io->lengath);
+    s.back(io->dsubcld, (const double *)d.dsubcld, 1, true, io->lengath);
+    s.back(io->jt, (const int32_t *)d.jt, 1, true, io->lengath);
+    s.back(io->maxg, (const int32_t *)d.maxg, 1, true, io->lengath);
+    s.back(io->ideep, (const int32_t *)d.ideep, 1, true, io->lengath);
+    return COLPHYS_OK;
+}
+
+int colphys_zm_conv_evap_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, double deltat,
+                                const colphys_zm_conv_evap_io *io)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
+    if (!io) return fail(COLPHYS_ERR_ARG, "null io");
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t ncd = (size_t)nchunks * pcols, pverp = pver + 1;
+    const size_t bytes = 8 * ncd * (4 * pverp + 14 * (size_t)pver + 8) + 64 * 256;
+    if ((rc = stage_reserve(bytes, bytes))) return rc;
+    Stager s(nchunks, pcols, ncol, g_pin_arena.p, g_dev_arena.p);
+    colphys_zm_conv_evap_io d = *io;
+    d.t = s.in(io->t, pver); d.pmid = s.in(io->pmid, pver); d.pdel = s.in(io->pdel, pver); d.q = s.in(io->q, pver);
+    d.prdprec = s.in(io->prdprec, pver); d.cldfrc = s.in(io->cldfrc, pver); d.landfrac = s.in(io->landfrac, 1);
+    d.prec = s.in(io->prec, 1);
+    double **mid_d[] = {&d.tend_s, &d.tend_s_snwprd, &d.tend_s_snwevmlt, &d.tend_q, &d.ntprprd, &d.ntsnprd};
+    for (auto pp : mid_d) *pp = s.out<double>(pver);
+    d.flxprec = s.out<double>(pverp); d.flxsnow = s.out<double>(pverp); d.snow = s.out<double>(1);
+    rc = colphys_zm_conv_evap_dev((int)ncd, pver, deltat, &d, nullptr);
+    if (rc) return rc;
+    const double *ms[] = {d.tend_s, d.tend_s_snwprd, d.tend_s_snwevmlt, d.tend_q, d.ntprprd, d.ntsnprd};
+    double *mh[] = {io->tend_s, io->tend_s_snwprd, io->tend_s_snwevmlt, io->tend_q, io->ntprprd, io->ntsnprd};
+    for (int f = 0; f < 6; ++f) s.back(mh[f], ms[f], pver, false, nullptr);
+    s.back(io->flxprec, (const double *)d.flxprec, pverp, false, nullptr);
+    s.back(io->flxsnow, (const double *)d.flxsnow, pverp, false, nullptr);
+    s.back(io->prec, (const double *)d.prec, 1, false, nullptr);
+    s.back(io->snow, (const double *)d.snow, 1, false, nullptr);
+    return COLPHYS_OK;
+}
+
+int colphys_momtran_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, double dt, const colphys_momtran_io *io)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
+    if (!io) return fail(COLPHYS_ERR_ARG, "null io");
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t ncd = (size_t)nchunks * pcols;
+    const size_t bytes = 8 * ncd * (20 * (size_t)pver + 8) + 4 * ncd * 4 + 64 * 256;
+    if ((rc = stage_reserve(bytes, bytes))) return rc;
+    Stager s(nchunks, pcols, ncol, g_pin_arena.p, g_dev_arena.p);
+    colphys_momtran_io d = *io;
+    // winds: CAM (pcols,pver,2) per chunk; the shim passes component-major (pcols,pver,nchunks,2)
+    d.winds = s.in_multi(io->winds, pver, 2);
+    d.mu = s.in(io->mu, pver); d.md = s.in(io->md, pver); d.du = s.in(io->du, pver); d.eu = s.in(io->eu, pver);
+    d.ed = s.in(io->ed, pver); d.dp = s.in(io->dp, pver); d.dsubcld = s.in(io->dsubcld, 1);
+    d.jt = s.in_i(io->jt, 1); d.mx = s.in_i(io->mx, 1); d.ideep = s.in_i(io->ideep, 1);
+    int32_t *dl = s.dc.take<int32_t>(nchunks);
+    HIPCHK(hipMemcpy(dl, io->lengath, 4 * (size_t)nchunks, hipMemcpyHostToDevice));
+    d.lengath = dl;
+    double *o3[5];
+    for (auto &p : o3) p = s.dc.take<double>(2 * ncd * pver);
+    d.dqdt = o3[0]; d.pguall = o3[1]; d.pgdall = o3[2]; d.icwu = o3[3]; d.icwd = o3[4];
+    d.seten = s.out<double>(pver);
+    rc = colphys_momtran_dev((int)ncd, pver, pcols, dt, &d, nullptr);
+    if (rc) return rc;
+    double *h3[] = {io->dqdt, io->pguall, io->pgdall, io->icwu, io->icwd};
+    for (int f = 0; f < 5; ++f)
+        for (int m = 0; m < 2; ++m) s.back(h3[f] + (size_t)m * ncd * pver, (const double *)(o3[f] + (size_t)m * ncd * pver), pver, false, nullptr);
+    s.back(io->seten, (const double *)d.seten, pver, false, nullptr);
+    return COLPHYS_OK;
+}
+
+static int aero_chunks(bool sw, int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
+    if (!g_aero_set) return fail(COLPHYS_ERR_NOTINIT, "colphys_aero_tables_set has not been called");
+    if (!io) return fail(COLPHYS_ERR_ARG, "null io");
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t ncd = (size_t)nchunks * pcols, pverp = pver + 1;
+    const int nm = g_A.nmodes, ns = g_A.nspec_max, nb = sw ? g_A.nswbands : g_A.nlwbands;
+    const size_t nout = sw ? 4 * (size_t)nb * pverp : (size_t)nb * pver;
+    const size_t bytes = 8 * ncd * ((3 + (size_t)nm * (ns + 2)) * pver + 2 * nout + 8) + 256 * 256;
+    if ((rc = stage_reserve(bytes, bytes))) return rc;
+    Stager s(nchunks, pcols, ncol, g_pin_arena.p, g_dev_arena.p);
+    colphys_modal_aero_io d = *io;
+    d.pdeldry = s.in(io->pdeldry, pver);
+    d.pmid = io->pmid ? s.in(io->pmid, pver) : nullptr;
+    d.t = io->t ? s.in(io->t, pver) : nullptr;
+    // specmmr (pcols,pver,nchunks,nspec_max,nmodes); dgnumwet/qaerwat (pcols,pver,nchunks,nmodes): field-major
+    d.specmmr = s.in_multi(io->specmmr, pver, nm * ns);
+    d.dgnumwet = s.in_multi(io->dgnumwet, pver, nm);
+    d.qaerwat = s.in_multi(io->qaerwat, pver, nm);
+    d.troplevchem = nullptr;
+    d.status = s.out<int32_t>(1);
+    const int nlevout = sw ? (int)pverp : pver;
+    double *o[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int f = 0; f < (sw ? 4 : 1); ++f) o[f] = s.dc.take<double>(ncd * nb * nlevout);
+    d.tauxar = o[0]; d.wa = o[1]; d.ga = o[2]; d.fa = o[3];
+    rc = sw ? colphys_modal_aero_sw_dev((int)ncd, pver, &d, nullptr) : colphys_modal_aero_lw_dev((int)ncd, pver, &d, nullptr);
+    if (rc) return rc;
+    // device [col][band][lev] -> Fortran (pcols, lev, nbands) per chunk
+    double *hdst[4] = {io->tauxar, io->wa, io->ga, io->fa};
+    std::vector<double> h(ncd * nb * nlevout);
+    for (int f = 0; f < (sw ? 4 : 1); ++f) {
+        HIPCHK(hipMemcpy(h.data(), o[f], h.size() * 8, hipMemcpyDeviceToHost));
+        for (int c = 0; c < nchunks; ++c)
+            for (int i = 0; i < ncol[c]; ++i)
+                for (int b = 0; b < nb; ++b)
+                    for (int k = 0; k < nlevout; ++k)
+                        hdst[f][(size_t)c * pcols * nlevout * nb + ((size_t)b * nlevout + k) * pcols + i] =
+                            h[(((size_t)c * pcols + i) * nb + b) * nlevout + k];
+    }
+    s.back(io->status, (const int32_t *)d.status, 1, false, nullptr);
+    return COLPHYS_OK;
+}
+int colphys_modal_aero_sw_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io) { return aero_chunks(true, nchunks, pcols, pver, ncol, io); }
+int colphys_modal_aero_lw_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io) { return aero_chunks(false, nchunks, pcols, pver, ncol, io); }
+
+}  // extern "C"

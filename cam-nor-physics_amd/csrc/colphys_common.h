@@ -1,0 +1,73 @@
+// colphys_common.h -- shared by the HIP translation units of libcolphys_hip.so (gfx950 only).
+//
+// Device data layout (DESIGN.md "Data layout in HBM"): one buffer per field, column-contiguous
+// [ncol][pver] (interfaces [ncol][pver+1]); a work item is one grid column.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/colphys.h"
+
+#define WAVE 64
+
+// Parameters as the kernels see them: colphys_zm_params plus the values zm_convi derives
+// (zm_conv.F90:145-155).  Passed BY VALUE as a kernel argument (wave-uniform => SGPRs / scalar loads).
+struct ZmDev {
+    // physconst
+    double cpair, epsilo, gravit, latice, latvap, tmelt, rair, cpwv, cpliq, rh2o, cpvir, zvir;
+    // tunables
+    double c0_lnd, c0_ocn, ke, ke_lnd, momcu, momcd, tiedke_add, capelmt, tau;
+    double tiedke_lnd, entrmn, alfadet, tentrm, plclmin, cin_threshd, parcel_hscale;
+    // derived
+    double rl, cpres, rgrav, rgas, grav, cp, tfreez, eps1, dcol, omeps;
+    int limcnv, num_cin, zm_org, no_deep_pbl, lparcel_pbl;
+};
+
+// 1-K saturation table zm_conv_evap's qsat interpolates in (spec: oracle/stubs/l0_arithmetic.F90)
+#define COLPHYS_PLENEST 249
+#define COLPHYS_TMIN_TBL 127.16
+#define COLPHYS_TMAX_TBL 375.16
+
+struct AeroDev {
+    int nmodes, nspec_max, nswbands, nlwbands, top_lev;
+    double rhoh2o, rga, rair, xrmin, xrmax;
+    const int *nspec, *spectype;
+    const double *sigmag, *specdens, *hygro, *specrefindex_sw, *specrefindex_lw;
+    const double *refrtabsw, *refitabsw, *refrtablw, *refitablw, *extpsw, *abspsw, *asmpsw, *absplw, *crefwsw, *crefwlw;
+};
+
+// ---- saturation vapour pressure: Goff-Gratch over water / ice (spec: oracle/stubs/l0_arithmetic.F90) ----
+__device__ inline double svp_water_gg(double t)
+{
+    const double tboil = 373.16;
+    return exp10(-7.90298 * (tboil / t - 1.0) + 5.02808 * log10(tboil / t)
+                 - 1.3816e-7 * (exp10(11.344 * (1.0 - t / tboil)) - 1.0)
+                 + 8.1328e-3 * (exp10(-3.49149 * (tboil / t - 1.0)) - 1.0)
+                 + log10(1013.246)) * 100.0;
+}
+
+// ---- launchers implemented in the k_*.hip files ------------------------------------------------------
+int launch_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspecies, const double *piln,
+                          const double *pint, const double *pmid, const double *pdel, const double *rpdel,
+                          const double *t, const double *q, const double *rair, double gravit, const double *zvir,
+                          double *zi, double *zm, hipStream_t st);
+
+struct ZmWorkspace {            // device scratch owned by the API layer (grow-only)
+    int *count;                 // [1]   number of first-pass triggered columns
+    int *list;                  // [ncol] their column indices (order irrelevant)
+    double *cape1, *cin1;       // [ncol]
+    int *lel1, *mx1;            // [ncol]
+    int *deep;                  // [ncol] 1 if the column ends in the gathered set
+    int *jt_f, *maxg_f;         // [ncol] full-layout copies
+    double *dsub_f;             // [ncol]
+    double *mu_f, *md_f, *du_f, *eu_f, *ed_f, *dp_f;  // [ncol][pver] full-layout plume profiles
+};
+int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io &io,
+                    const ZmWorkspace &ws, hipStream_t st, hipEvent_t *ev /* 4 events or null */);
+
+int launch_zm_conv_evap(const ZmDev &P, const double *estbl_dev, int ncol, int pver, double deltat,
+                        const colphys_zm_conv_evap_io &io, hipStream_t st);
+int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, const colphys_momtran_io &io, hipStream_t st);
+int launch_modal_aero_sw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);
+int launch_modal_aero_lw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);

@@ -1,0 +1,413 @@
+// k_scans.hip -- the three bandwidth-bound vertical scans of the path, for gfx950:
+//
+//   geopotential_t   /root/reference/physics/geopotential.F90:153-310   bottom-up hydrostatic integration
+//   zm_conv_evap     /root/reference/physics/zm_conv.F90:1712-1972      top-down precipitation flux / evaporation
+//   momtran          /root/reference/physics/zm_conv.F90:2315-2715      up/down in-cloud wind recurrences
+//
+// HBM layout is column-contiguous [ncol][pver]; the scans are serial in k and independent across columns, so
+// the mapping is one lane per column with the block's columns staged through LDS:
+//   - the block's slab of a field ([TILE columns][nlev], contiguous in HBM) is read with fully coalesced
+//     loads by all lanes and written to LDS transposed-by-stride (row stride odd => ds_read_b64 of one level
+//     by 32 consecutive columns is bank-conflict free);
+//   - each lane then walks its own column in LDS, keeping the reference's operation order exactly
+//     (no tree scans: the recurrences are evaluated serially per column, so results do not depend on the
+//     mapping);
+//   - outputs go back through the same LDS tiles and leave with coalesced stores.
+// Algorithmic bytes per column (fp64): DESIGN.md "Kernels".
+#include "colphys_common.h"
+
+namespace {
+
+constexpr int TILE = 32;      // columns per block
+constexpr int NT = 64;        // threads per block (one wave): all lanes move data, lanes < TILE scan
+
+__device__ __forceinline__ int ldk_of(int nlev) { return (nlev & 1) ? nlev : nlev + 1; }
+
+// global [nc][nlev] contiguous slab -> LDS tile s[c*ldk + k]
+__device__ __forceinline__ void tile_in(double *s, const double *g, int nc, int nlev, int ldk)
+{
+    const int n = nc * nlev;
+    for (int i = threadIdx.x; i < n; i += NT) {
+        const int c = i / nlev, k = i - c * nlev;
+        s[c * ldk + k] = g[i];
+    }
+}
+__device__ __forceinline__ void tile_out(double *g, const double *s, int nc, int nlev, int ldk)
+{
+    const int n = nc * nlev;
+    for (int i = threadIdx.x; i < n; i += NT) {
+        const int c = i / nlev, k = i - c * nlev;
+        g[i] = s[c * ldk + k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// geopotential_t
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void geopotential_kernel(int ncol, int pver, int dycore_kind, int nspecies,
+                                                         const double *__restrict__ piln, const double *__restrict__ pint,
+                                                         const double *__restrict__ pmid, const double *__restrict__ pdel,
+                                                         const double *__restrict__ rpdel, const double *__restrict__ t,
+                                                         const double *__restrict__ q, const double *__restrict__ rair,
+                                                         double gravit, const double *__restrict__ zvir,
+                                                         double *__restrict__ zi, double *__restrict__ zm)
+{
+    extern __shared__ double smem[];
+    const int col0 = blockIdx.x * TILE;
+    const int nc = min(TILE, ncol - col0);
+    const int pverp = pver + 1;
+    const int ld = ldk_of(pver), ldp = ldk_of(pverp);
+    const size_t L = (size_t)pver, LP = (size_t)pverp, F = (size_t)ncol * L;
+
+    // tiles: A = hkl source 1 (piln | pdel), B = hkl source 2 (pint | pmid), R = rpdel, T, Q(tvfac), RA, ZV, ZI
+    double *sA = smem;                    // [TILE][ldp]
+    double *sB = sA + TILE * ldp;         // [TILE][ldp]
+    double *sR = sB + TILE * ldp;         // [TILE][ld]
+    double *sT = sR + TILE * ld;
+    double *sQ = sT + TILE * ld;
+    double *sRA = sQ + TILE * ld;
+    double *sZV = sRA + TILE * ld;
+    double *sZI = sZV + TILE * ld;        // [TILE][ldp]   (zm reuses sT)
+
+    if (dycore_kind == COLPHYS_DYCORE_FV) {
+        tile_in(sA, piln + col0 * LP, nc, pverp, ldp);
+        tile_in(sB, pint + col0 * LP, nc, pverp, ldp);
+        tile_in(sR, rpdel + col0 * L, nc, pver, ld);
+    } else {
+        tile_in(sA, pdel + col0 * L, nc, pver, ldp);
+        tile_in(sB, pmid + col0 * L, nc, pver, ldp);
+    }
+    tile_in(sT, t + col0 * L, nc, pver, ld);
+    tile_in(sQ, q + col0 * L, nc, pver, ld);
+    tile_in(sRA, rair + col0 * L, nc, pver, ld);
+    tile_in(sZV, zvir + col0 * L, nc, pver, ld);
+    __syncthreads();
+
+    if (dycore_kind == COLPHYS_DYCORE_SE) {          // generalised virtual temperature :255-275, 301
+        // tvfac needs sums over the thermodynamically active species: accumulate them straight from HBM,
+        // element-wise (coalesced), before the scan; sQ ends up holding tvfac/.. inputs: q1, then tvfac
+        const int n = nc * pver;
+        for (int i = threadIdx.x; i < n; i += NT) {
+            const int c = i / pver, k = i - c * pver;
+            double qfac = 1.0, sum_dry = 1.0;
+            for (int idx = 0; idx < nspecies; ++idx) qfac = qfac - q[idx * F + col0 * L + i];
+            qfac = 1.0 / qfac;
+            for (int idx = 0; idx < nspecies; ++idx) sum_dry = sum_dry + q[idx * F + col0 * L + i] * qfac;
+            sum_dry = 1.0 / sum_dry;
+            sQ[c * ld + k] = (1.0 + (sZV[c * ld + k] + 1.0) * sQ[c * ld + k] * qfac) * sum_dry;
+        }
+        __syncthreads();
+    }
+
+    const int c = threadIdx.x;
+    if (c < nc) {
+        double zi_kp1 = 0.0;                         // :207-209
+        sZI[c * ldp + pver] = 0.0;
+        for (int k = pver - 1; k >= 0; --k) {        // 0-based level index here
+            double hkl, hkk, tvfac;
+            if (dycore_kind == COLPHYS_DYCORE_FV) {  // :222-226
+                hkl = sA[c * ldp + k + 1] - sA[c * ldp + k];
+                hkk = 1.0 - sB[c * ldp + k] * hkl * sR[c * ld + k];
+            } else {                                 // :232-235
+                hkl = sA[c * ldp + k] / sB[c * ldp + k];
+                hkk = 0.5 * hkl;
+            }
+            if (dycore_kind == COLPHYS_DYCORE_SE) tvfac = sQ[c * ld + k];
+            else tvfac = 1.0 + sZV[c * ld + k] * sQ[c * ld + k];     // :241
+            const double rog = sRA[c * ld + k] / gravit;             // :203
+            const double tv = sT[c * ld + k] * tvfac;
+            sT[c * ld + k] = zi_kp1 + rog * tv * hkk;                // zm :244
+            zi_kp1 = zi_kp1 + rog * tv * hkl;                        // zi :245
+            sZI[c * ldp + k] = zi_kp1;
+        }
+    }
+    __syncthreads();
+    tile_out(zi + col0 * LP, sZI, nc, pverp, ldp);
+    tile_out(zm + col0 * L, sT, nc, pver, ld);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// zm_conv_evap (old_snow path; kemask = ke unless zm_org)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void zm_conv_evap_kernel(ZmDev P, const double *__restrict__ estbl, int ncol, int pver,
+                                                         double deltat, colphys_zm_conv_evap_io io)
+{
+    extern __shared__ double smem[];
+    __shared__ double s_estbl[COLPHYS_PLENEST + 1];
+    const int col0 = blockIdx.x * TILE;
+    const int nc = min(TILE, ncol - col0);
+    const int pverp = pver + 1;
+    const int ld = ldk_of(pver), ldp = ldk_of(pverp);
+    const size_t L = (size_t)pver, LP = (size_t)pverp;
+
+    double *sT = smem;                 // t        -> tend_s
+    double *sPM = sT + TILE * ld;      // pmid     -> tend_s_snwprd
+    double *sPD = sPM + TILE * ld;     // pdel     -> tend_s_snwevmlt
+    double *sQ = sPD + TILE * ld;      // q        -> tend_q
+    double *sPR = sQ + TILE * ld;      // prdprec  -> ntprprd
+    double *sCL = sPR + TILE * ld;     // cldfrc   -> ntsnprd
+    double *sFP = sCL + TILE * ld;     // flxprec [ldp]
+    double *sFS = sFP + TILE * ldp;    // flxsnow [ldp]
+
+    for (int i = threadIdx.x; i <= COLPHYS_PLENEST; i += NT) s_estbl[i] = estbl[i];
+    tile_in(sT, io.t + col0 * L, nc, pver, ld);
+    tile_in(sPM, io.pmid + col0 * L, nc, pver, ld);
+    tile_in(sPD, io.pdel + col0 * L, nc, pver, ld);
+    tile_in(sQ, io.q + col0 * L, nc, pver, ld);
+    tile_in(sPR, io.prdprec + col0 * L, nc, pver, ld);
+    tile_in(sCL, io.cldfrc + col0 * L, nc, pver, ld);
+    __syncthreads();
+
+    const int c = threadIdx.x;
+    if (c < nc) {
+        const int col = col0 + c;
+        const double tmelt = P.tmelt, gravit = P.gravit, latice = P.latice, latvap = P.latvap;
+        const double landfrac = io.landfrac[col];
+        const double prec = io.prec[col] * 1000.0;                               // :1797
+        double evpvint = 0.0, flxprec = 0.0, flxsnow = 0.0;
+        sFP[c * ldp] = 0.0;                                                      // :1812-1813
+        sFS[c * ldp] = 0.0;
+        for (int k = 0; k < pver; ++k) {
+            const double tk = sT[c * ld + k], pmid = sPM[c * ld + k], pdel = sPD[c * ld + k], qk = sQ[c * ld + k],
+                         prdprec = sPR[c * ld + k], cldfrc = sCL[c * ld + k];
+            // qsat: 1-K table with water<->ice transition (:1804; spec oracle/stubs/l0_arithmetic.F90)
+            double es, qs;
+            {
+                const double t_tmp = fmax(fmin(tk, COLPHYS_TMAX_TBL) - COLPHYS_TMIN_TBL, 0.0);
+                const int i = (int)t_tmp + 1;
+                if (i < COLPHYS_PLENEST) {
+                    const double weight = fmin(t_tmp - trunc(t_tmp), 1.0);
+                    es = (1.0 - weight) * s_estbl[i] + weight * s_estbl[i + 1];
+                } else {
+                    es = s_estbl[COLPHYS_PLENEST];
+                }
+                if ((pmid - es) <= 0.0) qs = 1.0;
+                else qs = P.epsilo * es / (pmid - P.omeps * es);
+            }
+            double fsnow_conv;                                                   // cldfrc_fice :1809
+            {
+                const double tmax_fsnow = tmelt, tmin_fsnow = tmelt - 5.0;
+                if (tk > tmax_fsnow) fsnow_conv = 0.0;
+                else if (tk < tmin_fsnow) fsnow_conv = 1.0;
+                else fsnow_conv = (tmax_fsnow - tk) / (tmax_fsnow - tmin_fsnow);
+            }
+            double flxsntm, snowmlt;                                             // :1821-1828
+            if (tk > tmelt) { flxsntm = 0.0; snowmlt = flxsnow * gravit / pdel; }
+            else { flxsntm = flxsnow; snowmlt = 0.0; }
+            double evplimit = fmax(1.0 - qk / (1.0 + qk) / qs, 0.0);             // :1854
+            const double kemask = P.zm_org ? (P.ke * (1.0 - landfrac) + P.ke_lnd * landfrac) : P.ke;
+            double evpprec = kemask * (1.0 - cldfrc) * evplimit * sqrt(flxprec); // :1868
+            evplimit = fmin(evplimit, flxprec * gravit / pdel);                  // :1885 (:1875-1878 disabled by tht_tweaks)
+            evplimit = fmin(evplimit, (prec - evpvint) * gravit / pdel);         // :1888
+            evpprec = fmin(evplimit, evpprec);
+            double evpsnow, work1, work2;
+            if (flxprec > 0.0) {                                                 // :1898-1905
+                work1 = fmin(fmax(0.0, flxsntm / flxprec), 1.0);
+                evpsnow = evpprec * work1;
+            } else {
+                evpsnow = 0.0;
+            }
+            evpvint = evpvint + evpprec * pdel / gravit;
+            const double ntprprd = prdprec - evpprec;
+            if (flxprec > 0.0) work1 = fmin(fmax(0.0, flxsnow / flxprec), 1.0);  // :1924-1935
+            else work1 = 0.0;
+            work2 = fmax(fsnow_conv, work1);
+            if (snowmlt > 0.0) work2 = 0.0;
+            const double ntsnprd = prdprec * work2 - evpsnow - snowmlt;
+            sPM[c * ld + k] = prdprec * work2 * latice;                          // tend_s_snwprd
+            sPD[c * ld + k] = -(evpsnow + snowmlt) * latice;                     // tend_s_snwevmlt
+            flxprec = flxprec + ntprprd * pdel / gravit;                         // :1943-1948
+            flxsnow = flxsnow + ntsnprd * pdel / gravit;
+            flxprec = fmax(flxprec, 0.0);
+            flxsnow = fmax(flxsnow, 0.0);
+            sFP[c * ldp + k + 1] = flxprec;
+            sFS[c * ldp + k + 1] = flxsnow;
+            sT[c * ld + k] = -evpprec * latvap + ntsnprd * latice;               // tend_s :1956
+            sQ[c * ld + k] = evpprec;                                            // tend_q
+            sPR[c * ld + k] = ntprprd;
+            sCL[c * ld + k] = ntsnprd;
+        }
+        io.prec[col] = flxprec / 1000.0;                                         // :1965-1966
+        io.snow[col] = flxsnow / 1000.0;
+    }
+    __syncthreads();
+    tile_out(io.tend_s + col0 * L, sT, nc, pver, ld);
+    tile_out(io.tend_s_snwprd + col0 * L, sPM, nc, pver, ld);
+    tile_out(io.tend_s_snwevmlt + col0 * L, sPD, nc, pver, ld);
+    tile_out(io.tend_q + col0 * L, sQ, nc, pver, ld);
+    tile_out(io.ntprprd + col0 * L, sPR, nc, pver, ld);
+    tile_out(io.ntsnprd + col0 * L, sCL, nc, pver, ld);
+    tile_out(io.flxprec + col0 * LP, sFP, nc, pverp, ldp);
+    tile_out(io.flxsnow + col0 * LP, sFS, nc, pverp, ldp);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// momtran: initialisation of the full-layout outputs (:2429-2443), element-wise
+// ------------------------------------------------------------------------------------------------------
+__global__ void momtran_init_kernel(size_t n2, size_t n1, colphys_momtran_io io)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        const double w = io.winds[i];
+        io.pguall[i] = 0.0; io.pgdall[i] = 0.0; io.dqdt[i] = 0.0; io.icwu[i] = w; io.icwd[i] = w;
+        if (i < n1) io.seten[i] = 0.0;
+    }
+}
+
+// momtran proper: one lane per GATHERED column; block = one wave handling up to 64 gathered rows.
+// Gathered rows are sparse (lengath <= pcols per chunk), so lanes map to (chunk, slot) pairs of a
+// chunk-aligned range; work profiles are private (the kernel touches ~10 % of the columns).
+template <int ML>
+__global__ __launch_bounds__(NT) void momtran_kernel(ZmDev P, int ncol, int pver, int pcols, double dt, colphys_momtran_io io)
+{
+    const int row = blockIdx.x * NT + threadIdx.x;           // gathered row index in the flat layout
+    if (row >= ncol) return;
+    const int ic = row / pcols, c0 = ic * pcols, slot = row - c0;
+    const int il2g = io.lengath[ic];
+    if (slot >= il2g) return;
+    const size_t L = (size_t)pver, F = (size_t)ncol * L;
+    const double mbsth = 1.e-15;
+
+    int ktm = pver, kbm = pver;                                                  // :2449-2454 (per chunk)
+    for (int i = 0; i < il2g; ++i) {
+        ktm = min(ktm, io.jt[c0 + i]);
+        kbm = min(kbm, io.mx[c0 + i]);
+    }
+    const size_t ii = (size_t)(c0 + io.ideep[row] - 1);
+    const double *mu = io.mu + row * L - 1, *md = io.md + row * L - 1, *du = io.du + row * L - 1,
+                 *eu = io.eu + row * L - 1, *ed = io.ed + row * L - 1, *dp = io.dp + row * L - 1;
+    const int mx = io.mx[row];
+
+    double cnst[ML], chat[ML], cond[ML], conu[ML], pgu[ML], pgd[ML];
+    double mflux[2][ML + 1], wind0[2][ML], windf[2][ML];
+    for (int m = 0; m < 2; ++m) {
+        for (int k = 0; k < ML; ++k) { wind0[m][k] = 0.0; windf[m][k] = 0.0; }
+        for (int k = 0; k < ML + 1; ++k) mflux[m][k] = 0.0;
+    }
+
+    for (int m = 0; m < 2; ++m) {
+        const double *qw = io.winds + m * F + ii * L - 1;
+        for (int k = 1; k <= pver; ++k) { cnst[k] = qw[k]; wind0[m][k] = cnst[k]; }           // :2461-2466
+        for (int k = 1; k <= pver; ++k) {                                                     // :2473-2488
+            const int km1 = max(1, k - 1);
+            chat[k] = 0.5 * (cnst[k] + cnst[km1]);
+            conu[k] = chat[k];
+            cond[k] = chat[k];
+        }
+        pgu[1] = 0.0;                                                                         // :2497-2499
+        pgd[1] = 0.0;
+        for (int k = 2; k <= pver - 1; ++k) {                                                 // :2501-2521
+            const int km1 = k - 1, kp1 = k + 1;
+            const double mududp = (mu[k] * (cnst[k] - cnst[km1]) / dp[km1] + mu[kp1] * (cnst[kp1] - cnst[k]) / dp[k]);
+            pgu[k] = -P.momcu * 0.5 * mududp;
+            const double mddudp = (md[k] * (cnst[k] - cnst[km1]) / dp[km1] + md[kp1] * (cnst[kp1] - cnst[k]) / dp[k]);
+            pgd[k] = -P.momcd * 0.5 * mddudp;
+        }
+        {                                                                                     // :2524-2535
+            const int k = pver, km1 = pver - 1;
+            const double mududp = mu[k] * (cnst[k] - cnst[km1]) / dp[km1];
+            pgu[k] = -P.momcu * mududp;
+            const double mddudp = md[k] * (cnst[k] - cnst[km1]) / dp[km1];
+            pgd[k] = -P.momcd * mddudp;
+        }
+        {                                                                                     // :2543-2558
+            const int k = 2, km1 = 1, kk = pver;
+            const double mupdudp = mu[kk] + du[kk] * dp[kk];
+            if (mupdudp > mbsth) conu[kk] = (+eu[kk] * cnst[kk] * dp[kk] + pgu[kk] * dp[kk]) / mupdudp;
+            // operator precedence of the reference kept as is (:2554)
+            if (md[k] < -mbsth) cond[k] = (-ed[km1] * cnst[km1] * dp[km1]) - pgd[km1] * dp[km1] / md[k];
+        }
+        for (int kk = pver - 1; kk >= 1; --kk) {                                              // :2563-2575
+            const int kkp1 = kk + 1;
+            const double mupdudp = mu[kk] + du[kk] * dp[kk];
+            if (mupdudp > mbsth)
+                conu[kk] = (mu[kkp1] * conu[kkp1] + eu[kk] * cnst[kk] * dp[kk] + pgu[kk] * dp[kk]) / mupdudp;
+        }
+        for (int k = 3; k <= pver; ++k) {                                                     // :2579-2589
+            const int km1 = k - 1;
+            if (md[k] < -mbsth)
+                cond[k] = (md[km1] * cond[km1] - ed[km1] * cnst[km1] * dp[km1] - pgd[km1] * dp[km1]) / md[k];
+        }
+        double *dq = io.dqdt + m * F + ii * L - 1, *pu = io.pguall + m * F + ii * L - 1,
+               *pd = io.pgdall + m * F + ii * L - 1, *iu = io.icwu + m * F + ii * L - 1, *id = io.icwd + m * F + ii * L - 1;
+        for (int k = 1; k <= pver; ++k) {
+            double dcondt = 0.0;
+            if (k >= ktm) {                                                                   // :2596-2611
+                const int kp1 = min(pver, k + 1);
+                dcondt = +(mu[kp1] * (conu[kp1] - chat[kp1]) - mu[k] * (conu[k] - chat[k])
+                           + md[kp1] * (cond[kp1] - chat[kp1]) - md[k] * (cond[k] - chat[k])) / dp[k];
+            }
+            if (k >= kbm && k == mx)                                                          // :2615-2627
+                dcondt = (1.0 / dp[k]) * (-mu[k] * (conu[k] - chat[k]) - md[k] * (cond[k] - chat[k]));
+            dq[k] = dcondt; pu[k] = -pgu[k]; pd[k] = -pgd[k]; iu[k] = conu[k]; id[k] = cond[k];   // :2632-2642
+        }
+        for (int k = ktm; k <= pver; ++k)                                                     // :2646-2653
+            mflux[m][k] = -mu[k] * (conu[k] - chat[k]) - md[k] * (cond[k] - chat[k]);
+        for (int k = ktm; k <= pver; ++k)                                                     // :2658-2666
+            windf[m][k] = cnst[k] - (mflux[m][k + 1] - mflux[m][k]) * dt / dp[k];
+    }
+    double *se = io.seten + ii * L - 1;
+    for (int k = ktm; k <= pver; ++k) {                                                       // :2675-2712
+        const int km1 = max(1, k - 1), kp1 = min(pver, k + 1);
+        const double utop = (wind0[0][k] + wind0[0][km1]) / 2.0, vtop = (wind0[1][k] + wind0[1][km1]) / 2.0;
+        const double ubot = (wind0[0][kp1] + wind0[0][k]) / 2.0, vbot = (wind0[1][kp1] + wind0[1][k]) / 2.0;
+        const double fket = utop * mflux[0][k] + vtop * mflux[1][k];
+        const double fkeb = ubot * mflux[0][k + 1] + vbot * mflux[1][k + 1];
+        const double ketend_cons = (fket - fkeb) / dp[k];
+        const double ketend = ((windf[0][k] * windf[0][k] + windf[1][k] * windf[1][k])
+                               - (wind0[0][k] * wind0[0][k] + wind0[1][k] * wind0[1][k])) * 0.5 / dt;
+        se[k] = ketend_cons - ketend;
+    }
+}
+
+inline int set_lds(const void *fn, size_t bytes)
+{
+    if (bytes > 64 * 1024)
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -1;
+    return 0;
+}
+
+}  // namespace
+
+int launch_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspecies, const double *piln,
+                          const double *pint, const double *pmid, const double *pdel, const double *rpdel,
+                          const double *t, const double *q, const double *rair, double gravit, const double *zvir,
+                          double *zi, double *zm, hipStream_t st)
+{
+    (void)nq;
+    const int ld = (pver & 1) ? pver : pver + 1, ldp = ((pver + 1) & 1) ? pver + 1 : pver + 2;
+    const size_t lds = (size_t)TILE * (3 * ldp + 5 * ld) * sizeof(double);
+    if (lds > 160 * 1024) return COLPHYS_ERR_UNSUPPORTED;
+    if (set_lds((const void *)geopotential_kernel, lds)) return COLPHYS_ERR_HIP;
+    const int nblk = (ncol + TILE - 1) / TILE;
+    hipLaunchKernelGGL(geopotential_kernel, dim3(nblk), dim3(NT), lds, st, ncol, pver, dycore_kind, nspecies, piln, pint,
+                       pmid, pdel, rpdel, t, q, rair, gravit, zvir, zi, zm);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}
+
+int launch_zm_conv_evap(const ZmDev &P, const double *estbl_dev, int ncol, int pver, double deltat,
+                        const colphys_zm_conv_evap_io &io, hipStream_t st)
+{
+    const int ld = (pver & 1) ? pver : pver + 1, ldp = ((pver + 1) & 1) ? pver + 1 : pver + 2;
+    const size_t lds = (size_t)TILE * (6 * ld + 2 * ldp) * sizeof(double);
+    if (lds > 150 * 1024) return COLPHYS_ERR_UNSUPPORTED;
+    if (set_lds((const void *)zm_conv_evap_kernel, lds)) return COLPHYS_ERR_HIP;
+    const int nblk = (ncol + TILE - 1) / TILE;
+    hipLaunchKernelGGL(zm_conv_evap_kernel, dim3(nblk), dim3(NT), lds, st, P, estbl_dev, ncol, pver, deltat, io);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}
+
+int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, const colphys_momtran_io &io, hipStream_t st)
+{
+    const size_t n1 = (size_t)ncol * pver, n2 = 2 * n1;
+    const int iblk = (int)((n2 + 255) / 256 < 2048 ? (n2 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(momtran_init_kernel, dim3(iblk), dim3(256), 0, st, n2, n1, io);
+    const int nblk = (ncol + NT - 1) / NT;
+    if (pver <= 32)
+        hipLaunchKernelGGL(momtran_kernel<36>, dim3(nblk), dim3(NT), 0, st, P, ncol, pver, pcols, dt, io);
+    else if (pver <= 72)
+        hipLaunchKernelGGL(momtran_kernel<76>, dim3(nblk), dim3(NT), 0, st, P, ncol, pver, pcols, dt, io);
+    else
+        hipLaunchKernelGGL(momtran_kernel<COLPHYS_MAX_PVER + 4>, dim3(nblk), dim3(NT), 0, st, P, ncol, pver, pcols, dt, io);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}

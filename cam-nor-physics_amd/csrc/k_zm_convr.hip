@@ -1,0 +1,1027 @@
+// k_zm_convr.hip -- Zhang-McFarlane deep convection (zm_convr) for gfx950.
+//
+// Replaces /root/reference/physics/zm_conv.F90:231-1709 and its callees buoyan_dilute :4425, parcel_dilute
+// :4824, entropy/enthalpy/ientropy/ienthalpy :5280-5570, cldprp :3024, closure :4028, q1q2_pjr :4262.
+// Line numbers in comments are zm_conv.F90.
+//
+// Whole-node dispatch: one work item = one grid column, independent of how the host groups columns into
+// chunks.  Three launches per call:
+//
+//   zm_trigger_kernel  every column : unit conversion, PBL-top index, first dilute-parcel ascent
+//                                     (buoyan_dilute/parcel_dilute), CAPE/CIN, trigger test; zero-fills the
+//                                     outputs; appends triggered columns to a device-side list.
+//   zm_plume_kernel    listed columns: cloud ensemble (cldprp), second parcel ascent with the ensemble's mean
+//                                     entrainment, re-trigger, cldprp again, closure, tendencies (q1q2_pjr),
+//                                     precipitation integrals; writes full-layout results.
+//   zm_gather_kernel   one block per host chunk: ascending-order compaction of the deep columns into the
+//                                     reference's per-chunk gathered layout (mu md du eu ed dp dsubcld jt maxg
+//                                     ideep lengath), zm_conv.F90:905-940,1096-1174.
+//
+// The dilute parcel is the cost (>= 84 % of the CPU time).  The reference makes two sweeps over
+// the levels (entrainment loop :4997-5148, then precipitation/freezing loop :5175-5273) through seven work
+// profiles; here the two sweeps are fused into ONE upward pass that carries the (k+1) values of both
+// sweeps in registers -- same arithmetic in the same order per level, no work profiles.  The only
+// profile the trigger needs afterwards is the parcel virtual temperature (for the neutral-buoyancy search
+// and the CAPE/CIN sums, :4773-4810); it is kept in LDS as [level][lane].
+//
+// Arithmetic: fp64, no FMA contraction (-ffp-contract=off), operation order of the reference.
+// Transcendentals are ROCm OCML (exp10/log10/log/exp/pow): not bit-identical to the host libm the
+// reference Fortran links, which is why parity is stated as 1e-10 relative, not bitwise.
+#include "colphys_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// L0 seams (spec: oracle/stubs/l0_arithmetic.F90)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void qsat_hPa(const ZmDev &P, double t, double p_hPa, double &es_hPa, double &qs)
+{   // qsat_hPa :5421-5437 around qsat_water(t, p[Pa])
+    const double p = p_hPa * 100.0;
+    double es = svp_water_gg(t);
+    if ((p - es) <= 0.0) qs = 1.0;
+    else qs = P.epsilo * es / (p - P.omeps * es);
+    es = fmin(es, p);
+    es_hPa = es * 0.01;
+}
+
+__device__ __forceinline__ double entropy_d(const ZmDev &P, double TK, double p, double qtot)
+{   // :5280-5300
+    const double pref = 1000.0;
+    double L = P.rl - (P.cpliq - P.cpwv) * (TK - P.tfreez);
+    double est, qst;
+    qsat_hPa(P, TK, p, est, qst);
+    double qv = fmin(qtot, qst);
+    double e = qv * p / (P.eps1 + qv);
+    return (P.cpres + qtot * P.cpliq) * log(TK / P.tfreez) - P.rgas * log((p - e) / pref) + L * qv / TK
+           - qv * P.rh2o * log(qv / qst);
+}
+
+__device__ __forceinline__ double enthalpy_d(const ZmDev &P, double TK, double p, double qtot, double z)
+{   // :5440-5457
+    double L = P.rl - (P.cpliq - P.cpwv) * (TK - P.tfreez);
+    double est, qst;
+    qsat_hPa(P, TK, p, est, qst);
+    double qv = fmin(qtot, qst);
+    return (P.cpres + qtot * P.cpliq) * TK + L * qv + (1.0 + qtot) * P.grav * z;
+}
+
+// ientropy :5304-5414 (KIND 0) / ienthalpy :5460-5570 (KIND 1): Brent's method, bracket Tfg +- 10 K.
+template <int KIND>
+__device__ __noinline__ int invert_brent(const ZmDev &P, double s, double p, double z, double qt, double &T, double &qst,
+                                         double Tfg)
+{
+    const int LOOPMAX = 100;
+    const double EPS = 3.e-8;
+    double a, b, c, d = 0.0, ebr = 0.0, fa, fb, fc, pbr, qbr, rbr, sbr, tol1, xm;
+    const double tol = 0.001;
+    bool converged = false;
+
+    auto feval = [&](double x) -> double {
+        if (KIND == 1) return enthalpy_d(P, x, p, qt, z) - s;
+        return entropy_d(P, x, p, qt) - s;
+    };
+
+    a = Tfg - 10;
+    b = Tfg + 10;
+    fa = feval(a);
+    fb = feval(b);
+    c = b;
+    fc = fb;
+
+    for (int i = 0; i <= LOOPMAX; ++i) {
+        if ((fb > 0.0 && fc > 0.0) || (fb < 0.0 && fc < 0.0)) {
+            c = a; fc = fa; d = b - a; ebr = d;
+        }
+        if (fabs(fc) < fabs(fb)) {
+            a = b; b = c; c = a; fa = fb; fb = fc; fc = fa;
+        }
+        tol1 = 2.0 * EPS * fabs(b) + 0.5 * tol;
+        xm = 0.5 * (c - b);
+        converged = (fabs(xm) <= tol1 || fb == 0.0);
+        if (converged) break;
+
+        if (fabs(ebr) >= tol1 && fabs(fa) > fabs(fb)) {
+            sbr = fb / fa;
+            if (a == c) {
+                pbr = 2.0 * xm * sbr;
+                qbr = 1.0 - sbr;
+            } else {
+                qbr = fa / fc;
+                rbr = fb / fc;
+                pbr = sbr * (2.0 * xm * qbr * (qbr - rbr) - (b - a) * (rbr - 1.0));
+                qbr = (qbr - 1.0) * (rbr - 1.0) * (sbr - 1.0);
+            }
+            if (pbr > 0.0) qbr = -qbr;
+            pbr = fabs(pbr);
+            if (2.0 * pbr < fmin(3.0 * xm * qbr - fabs(tol1 * qbr), fabs(ebr * qbr))) {
+                ebr = d; d = pbr / qbr;
+            } else {
+                d = xm; ebr = d;
+            }
+        } else {
+            d = xm; ebr = d;
+        }
+        a = b;
+        fa = fb;
+        b = b + ((fabs(d) > tol1) ? d : copysign(tol1, xm));
+        fb = feval(b);
+    }
+    T = b;
+    double est;
+    qsat_hPa(P, T, p, est, qst);
+    return converged ? 0 : COLPHYS_STATUS_BRENT_NOT_CONVERGED;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// One column's inputs, 1-based level index.  p, z, pf, zf are the unit-converted fields of :825-837.
+// ------------------------------------------------------------------------------------------------------
+struct ColIn {
+    const double *t, *q, *pap, *paph, *zm, *zi, *dpp;
+    double zs, tpert, landfrac, pblh;
+    int pver, msg;
+    __device__ __forceinline__ double T(int k) const { return t[k]; }
+    __device__ __forceinline__ double Q(int k) const { return q[k]; }
+    __device__ __forceinline__ double Pm(int k) const { return pap[k] * 0.01; }
+    __device__ __forceinline__ double Pf(int k) const { return paph[k] * 0.01; }
+    __device__ __forceinline__ double Z(int k) const { return zm[k] + zs; }
+    __device__ __forceinline__ double Zf(int k) const { return zi[k] + zs; }
+};
+
+struct BuoyRes {
+    double cape, cin, tl;
+    int lcl, lel, mx, lon, status;
+};
+
+__device__ __forceinline__ double moist_static_energy_total(const ZmDev &P, double t, double q, double z)
+{   // :4681-4682
+    return (P.cp + q * P.cpliq) * t / (1.0 + q) + (1.0 + q / P.eps1) / (1.0 + q) * P.grav * z
+           + (P.rl - (P.cpliq - P.cpwv) * (t - P.tfreez)) * q;
+}
+
+// buoyan_dilute :4425-4819 with parcel_dilute :4824-5277 fused into one upward pass.
+//   dmpdz    : parcel entrainment rate (/m); level-uniform in both calls of the reference (:544, :1074)
+//   s_tpv    : LDS, element for level k at s_tpv[k*WAVE]  (caller passes base + lane)
+//   tp, qstp : optional 1-based outputs (parcel temperature / saturation mixing ratio), nullptr to skip
+template <bool STORE_TP>
+__device__ void buoyan_dilute_d(const ZmDev &P, const ColIn &c, double pblt, double dmpdz, double cin_in,
+                                double *s_tpv, double *tp, double *qstp, BuoyRes &r)
+{
+    const int pver = c.pver, msg = c.msg;
+    const int npblt = (int)lrint(pblt);
+    const double lwmax = 1.e-3, tscool = 0.0;
+    double hmax = 0.0, pl, ql;
+    int status = 0;
+
+    r.lon = min(pver, npblt + 2);                                   // :4578
+    r.lel = pver;
+    r.mx = r.lon;
+    r.cape = 0.0;
+    r.cin = cin_in;
+
+    double parcel_ztop = 0.0, hpar = 0.0, qpar = 0.0;
+    if (P.lparcel_pbl) {                                            // :4586-4588, 4638-4673
+        double pbl_dz = c.Z(npblt) - c.zs;
+        double parcel_dz = fmax(c.zi[pver], P.parcel_hscale * pbl_dz);
+        parcel_ztop = parcel_dz + c.zs;
+        double parcel_hdp = 0.0, parcel_dp = 0.0, parcel_qdp = 0.0;
+        int ipar = pver;
+        for (int k = pver; k >= msg + 1; --k) {
+            if (c.zi[k + 1] <= parcel_dz) {
+                double hmn_lev = moist_static_energy_total(P, c.T(k), c.Q(k), c.Z(k));
+                double dp_lev = c.Pf(k + 1) - c.Pf(k);
+                double hmn_zdp = hmn_lev * dp_lev;
+                double q_zdp = c.Q(k) * dp_lev;
+                double dp_zfrac;
+                ipar = k;
+                if (k == pver) dp_zfrac = 1.0;
+                else dp_zfrac = fmin(1.0, (parcel_dz - c.zi[k + 1]) / (c.zi[k] - c.zi[k + 1]));
+                parcel_hdp = parcel_hdp + hmn_zdp * dp_zfrac;
+                parcel_qdp = parcel_qdp + q_zdp * dp_zfrac;
+                parcel_dp = parcel_dp + dp_lev * dp_zfrac;
+            }
+        }
+        hpar = parcel_hdp / parcel_dp;
+        qpar = parcel_qdp / parcel_dp;
+        r.mx = ipar;
+    } else {                                                        // :4677-4689
+        for (int k = r.lon; k >= max(npblt, msg + 1); --k) {
+            double hmn = moist_static_energy_total(P, c.T(k), c.Q(k), c.Z(k));
+            if (hmn > hmax) { hmax = hmn; r.mx = k; }
+        }
+    }
+    const int klaunch = r.mx;
+    r.lcl = klaunch;                                                // :4703-4717
+    if (P.lparcel_pbl) {
+        r.tl = (hpar - P.rl * qpar - P.grav * parcel_ztop) / P.cp;
+        ql = qpar;
+    } else {
+        r.tl = c.T(klaunch);
+        ql = c.Q(klaunch);
+    }
+    pl = c.Pm(klaunch);
+
+    // ---- fused parcel_dilute ---------------------------------------------------------------------
+    double zl = 0.0, mp = 0.0, qtp = 0.0, sp = 0.0, sp0, qtp0, mp0;
+    double t_kp1, q_kp1, p_kp1, z_kp1;                 // environment at k+1
+    double tmix1_kp1, qsmix1_kp1, qtmix_kp1, smix1_kp1; // sweep-1 values at k+1
+    double xsh2o_kp1 = 0.0, ds_xsh2o_kp1 = 0.0, ds_freeze_kp1 = 0.0, qsmix2_kp1;   // sweep-2 values at k+1
+    {
+        const int k = klaunch;                                      // :5002-5038, 5180-5200
+        const double tk = c.T(k), qk = c.Q(k), pk = c.Pm(k), zk = c.Z(k);
+        double est;
+        if (P.lparcel_pbl) {
+            qtp0 = ql;
+            sp0 = enthalpy_d(P, r.tl, pl, qtp0, zl);
+        } else {
+            qtp0 = qk;
+            sp0 = enthalpy_d(P, tk, pk, qtp0, zk);
+        }
+        mp0 = 1.0;
+        smix1_kp1 = sp0;
+        qtmix_kp1 = qtp0;
+        tmix1_kp1 = tk;
+        qsat_hPa(P, tmix1_kp1, pk, est, qsmix1_kp1);
+        qsmix2_kp1 = qsmix1_kp1;
+        t_kp1 = tk; q_kp1 = qk; p_kp1 = pk; z_kp1 = zk;
+        const double tpk = tmix1_kp1, qstpk = qk;
+        s_tpv[k * WAVE] = (tpk + c.tpert) * (1.0 + qstpk / P.eps1) / (1.0 + qstpk);   // :5194
+        if (STORE_TP) { tp[k] = tpk; qstp[k] = qstpk; }
+    }
+    for (int k = klaunch - 1; k >= msg + 1; --k) {
+        const double tk = c.T(k), qk = c.Q(k), pk = c.Pm(k), zk = c.Z(k);
+        // -- sweep 1: entrain, mix enthalpy, invert for T (:5042-5106)
+        const double dp = (pk - p_kp1);
+        const double qtenv = 0.5 * (qk + q_kp1);
+        const double tenv = 0.5 * (tk + t_kp1);
+        const double penv = 0.5 * (pk + p_kp1);
+        const double zenv = 0.5 * (zk + z_kp1);
+        const double senv = enthalpy_d(P, tenv, penv, qtenv, zenv);
+        const double dpdz = -(penv * P.grav) / (P.rgas * tenv);
+        const double dzdp = 1.0 / dpdz;
+        const double dmpdp = dmpdz * dzdp;
+        sp = sp - dmpdp * dp * senv;
+        qtp = qtp - dmpdp * dp * qtenv;
+        mp = mp - dmpdp * dp;
+        const double smix1 = (sp0 + sp) / (mp0 + mp);
+        const double qtmix = (qtp0 + qtp) / (mp0 + mp);
+        double tmix, qsmix;
+        status |= invert_brent<1>(P, smix1, pk, zk, qtmix, tmix, qsmix, tmix1_kp1);
+
+        if (qsmix <= qtmix && qsmix1_kp1 > qtmix_kp1) {             // LCL :5111-5133
+            r.lcl = k;
+            const double qxsk = qtmix - qsmix;
+            const double qxskp1 = qtmix_kp1 - qsmix1_kp1;
+            const double dqxsdp = (qxsk - qxskp1) / dp;
+            pl = p_kp1 - qxskp1 / dqxsdp;
+            zl = z_kp1 - qxskp1 / dqxsdp * dzdp;
+            const double dsdp = (smix1 - smix1_kp1) / dp;
+            const double dqtdp = (qtmix - qtmix_kp1) / dp;
+            const double slcl = smix1_kp1 + dsdp * (pl - p_kp1);
+            const double qtlcl = qtmix_kp1 + dqtdp * (pl - p_kp1);
+            double qslcl;
+            status |= invert_brent<1>(P, slcl, pl, zl, qtlcl, r.tl, qslcl, tmix);
+        }
+        tmix1_kp1 = tmix; qsmix1_kp1 = qsmix; qtmix_kp1 = qtmix; smix1_kp1 = smix1;
+
+        // -- sweep 2: rain-out and freezing, two iterations, invert entropy for T (:5202-5267)
+        const double smix2 = entropy_d(P, tmix, pk, qtmix);
+        double xsh2o = 0.0, ds_xsh2o = 0.0, ds_freeze = 0.0, new_s = 0.0, new_q = 0.0;
+#pragma unroll 1
+        for (int ii = 0; ii < 2; ++ii) {
+            xsh2o = fmax(0.0, qtmix - qsmix - lwmax);
+            ds_xsh2o = ds_xsh2o_kp1 - P.cpliq * log(tmix / P.tfreez) * fmax(0.0, (xsh2o - xsh2o_kp1));
+            if (tmix <= P.tfreez + tscool && ds_freeze_kp1 == 0.0)
+                ds_freeze = (P.latice / tmix) * fmax(0.0, qtmix - qsmix - xsh2o);
+            if (tmix <= P.tfreez + tscool && ds_freeze_kp1 != 0.0)
+                ds_freeze = ds_freeze_kp1 + (P.latice / tmix) * fmax(0.0, (qsmix2_kp1 - qsmix));
+            new_s = smix2 + ds_xsh2o + ds_freeze;
+            new_q = qtmix - xsh2o;
+            const double tfguess = tmix;
+            status |= invert_brent<0>(P, new_s, pk, 0.0, new_q, tmix, qsmix, tfguess);
+        }
+        xsh2o_kp1 = xsh2o; ds_xsh2o_kp1 = ds_xsh2o; ds_freeze_kp1 = ds_freeze; qsmix2_kp1 = qsmix;
+
+        const double tpk = tmix;
+        const double qstpk = (new_q > qsmix) ? qsmix : new_q;       // :5249-5253
+        s_tpv[k * WAVE] = (tpk + c.tpert) * (1.0 + qstpk / P.eps1) / (1.0 + new_q);     // :5263
+        if (STORE_TP) { tp[k] = tpk; qstp[k] = qstpk; }
+
+        t_kp1 = tk; q_kp1 = qk; p_kp1 = pk; z_kp1 = zk;
+    }
+    if (STORE_TP) {
+        for (int k = pver; k > klaunch; --k) { tp[k] = c.T(k); qstp[k] = c.Q(k); }     // :4597-4598
+        for (int k = msg; k >= 1; --k) { tp[k] = c.T(k); qstp[k] = c.Q(k); }
+    }
+
+    // ---- buoyancy, neutral levels, CAPE / CIN (:4742-4816) -----------------------------------------
+    const bool plge600 = (pl >= P.plclmin);
+    if (STORE_TP && !plge600) {
+        for (int k = pver; k >= msg + 1; --k) { tp[k] = c.T(k); qstp[k] = c.Q(k); }     // :4760-4761
+    }
+    // buoy(k) overwrites tpv(k) in LDS; zero outside [msg+1, mx]
+    for (int k = pver; k >= msg + 1; --k) {
+        double b = 0.0;
+        if (k <= klaunch && plge600) {
+            const double tk = c.T(k), qk = c.Q(k);
+            const double tv = tk * (1.0 + qk / P.eps1) / (1.0 + qk);
+            b = s_tpv[k * WAVE] - tv + P.tiedke_add;
+        }
+        s_tpv[k * WAVE] = b;
+    }
+    int lelten[6];
+    double capeten[6], cinten[6];
+#pragma unroll
+    for (int n = 1; n <= 5; ++n) { lelten[n] = pver; capeten[n] = 0.0; cinten[n] = 0.0; }
+    int knt = 0;
+    if (plge600) {
+        for (int k = msg + 2; k <= pver; ++k) {                     // :4773-4782
+            if (k < r.lcl) {
+                const double bk = s_tpv[k * WAVE];
+                const double bkp1 = (k + 1 <= pver) ? s_tpv[(k + 1) * WAVE] : 0.0;
+                if (bkp1 > 0.0 && bk <= 0.0) {
+                    knt = min(P.num_cin, knt + 1);
+                    lelten[knt] = k;
+                }
+            }
+        }
+        for (int n = 1; n <= P.num_cin; ++n) {                      // :4785-4796
+            double ct = 0.0, ci = 0.0;
+            for (int k = max(msg + 1, lelten[n] + 1); k <= klaunch; ++k) {
+                const double bk = s_tpv[k * WAVE];
+                const double lg = log(c.Pf(k + 1) / c.Pf(k));
+                ct = ct + P.rgas * bk * lg;
+                ci = ci - P.rgas * fmin(bk, 0.0) * lg;
+            }
+            capeten[n] = ct;
+            cinten[n] = ci;
+        }
+    }
+    for (int n = 1; n <= P.num_cin; ++n) {                          // :4802-4810
+        if (capeten[n] > r.cape) {
+            r.cape = capeten[n];
+            r.cin = cinten[n];
+            r.lel = lelten[n];
+        }
+    }
+    r.cape = fmax(r.cape, 0.0);
+    r.status = status;
+}
+
+__device__ __forceinline__ double pbl_top_index(const ColIn &c)
+{   // :777, 839-843
+    double pblt = c.pver;
+    for (int k = c.pver - 1; k >= c.msg + 1; --k)
+        if (fabs(c.Z(k) - c.zs - c.pblh) < (c.Zf(k) - c.Zf(k + 1)) * 0.5) pblt = k;
+    return pblt;
+}
+
+__device__ __forceinline__ ColIn make_colin(const ZmDev &P, const colphys_zm_convr_io &io, int col, int pver)
+{
+    ColIn c;
+    const size_t L = (size_t)pver, LP = (size_t)pver + 1;
+    c.t = io.t + col * L - 1;      c.q = io.qh + col * L - 1;   c.pap = io.pap + col * L - 1;
+    c.zm = io.zm + col * L - 1;    c.dpp = io.dpp + col * L - 1;
+    c.paph = io.paph + col * LP - 1; c.zi = io.zi + col * LP - 1;
+    c.zs = io.geos[col] * P.rgrav;  // :826
+    c.tpert = io.tpert[col]; c.landfrac = io.landfrac[col]; c.pblh = io.pblh[col];
+    c.pver = pver; c.msg = P.limcnv - 1;
+    return c;
+}
+
+// coalesced fill of n doubles starting at p by the whole block
+__device__ __forceinline__ void block_fill(double *p, size_t n, double v)
+{
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Kernel 1: trigger
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void zm_trigger_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io,
+                                                         ZmWorkspace ws)
+{
+    extern __shared__ double smem[];            // [(pver+2)][WAVE]
+    const int col0 = blockIdx.x * WAVE;
+    const int nb = min(WAVE, ncol - col0);
+    const int lane = threadIdx.x;
+    const int col = col0 + lane;
+    const size_t L = (size_t)pver, LP = (size_t)pver + 1;
+
+    // zero-fill every output of this block's columns, coalesced (:559-563, 625-650, 771-784 and the
+    // gathered arrays, whose slots beyond lengath the reference leaves stale)
+    {
+        double *mid[] = {io.qtnd, io.heat, io.cme, io.zdu, io.rprd, io.dlf, io.ql, io.dif, io.dnlf, io.dnif, io.eurt,
+                         io.mu, io.md, io.du, io.eu, io.ed, io.dp};
+        for (double *p : mid) block_fill(p + col0 * L, nb * L, 0.0);
+        block_fill(io.mcon + col0 * LP, nb * LP, 0.0);
+        block_fill(io.pflx + col0 * LP, nb * LP, 0.0);
+    }
+    if (lane < nb) {
+        io.prec[col] = 0.0; io.rliq[col] = 0.0; io.rice[col] = 0.0;
+        io.jctop[col] = pver; io.jcbot[col] = 1;
+        io.dsubcld[col] = 0.0; io.jt[col] = 0; io.maxg[col] = 0; io.ideep[col] = 0;
+        ws.deep[col] = 0;
+    }
+    if (lane >= nb) return;
+
+    const ColIn c = make_colin(P, io, col, pver);
+    const double pblt = pbl_top_index(c);
+    BuoyRes r;
+    buoyan_dilute_d<false>(P, c, pblt, -P.tentrm, 0.0, smem + lane, nullptr, nullptr, r);   // :544, 886
+
+    io.cape[col] = r.cape;
+    io.status[col] = r.status;
+    ws.cape1[col] = r.cape; ws.cin1[col] = r.cin; ws.lel1[col] = r.lel; ws.mx1[col] = r.mx;
+    if (r.cape > P.capelmt && r.cin < r.cape * P.cin_threshd) {     // :908-915
+        const int slot = atomicAdd(ws.count, 1);
+        ws.list[slot] = col;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// cldprp :3024-4026 (non-microphysics path), one column, private work profiles
+// ------------------------------------------------------------------------------------------------------
+template <int ML>
+struct CldOut {
+    double mu[ML], eu[ML], du[ML], md[ML], ed[ML], sd[ML], qd[ML], mc[ML], qu[ML], su[ML], qst[ML], ql[ML],
+        cmeg[ML], pflx[ML], evp[ML], cu[ML], rprd[ML], qcde[ML];
+    int jt, jlcl, j0, jd;
+};
+
+template <int ML>
+__device__ void cldprp_d(const ZmDev &P, int pver, int msg, const double *q, const double *t, const double *p,
+                         const double *z, const double *s, const double *zf, const double *shat, const double *qhat,
+                         int jb, int lel, double landfrac, CldOut<ML> &o)
+{
+    double gamma[ML], dz[ML], hu[ML], hd[ML], eps[ML], f[ML], k1[ML], i2[ML], i3[ML], i4[ML], qsthat[ML], hsthat[ML],
+        gamhat[ML], qds[ML], mcp[ML], mrl[ML], tu[ML], td[ML], hmn[ML], hsat[ML];
+    double hmin, expdif = 0.0, expnum, ftemp, eps0, rmue, zuef, zdef, epsm = 0.0, ratmjb, est, totpcp, totevp, ql1,
+           estu, qstu, mdt;
+    const int mx = jb;
+    const double rd = P.rgas, grav = P.grav, cp = P.cp, rl = P.rl, dcol = P.dcol, eps1 = P.eps1;
+    const double zvir = P.zvir, cpvir = P.cpvir, tmelt = P.tmelt;
+    const double small = 1.e-20;
+
+    const double c0mask = P.c0_ocn * (1.0 - landfrac) + P.c0_lnd * landfrac;                 // :3239-3240
+    const double tiedke_msk = P.tiedke_add * (1.0 - landfrac) + P.tiedke_lnd * landfrac;
+
+    for (int k = 1; k <= pver; ++k) dz[k] = zf[k] - zf[k + 1];
+
+    for (int k = 1; k <= pver; ++k) {                                                        // :3256-3314
+        k1[k] = 0.0; i2[k] = 0.0; i3[k] = 0.0; i4[k] = 0.0;
+        o.mu[k] = 0.0; f[k] = 0.0; eps[k] = 0.0; o.eu[k] = 0.0; o.du[k] = 0.0; o.ql[k] = 0.0; o.cu[k] = 0.0;
+        o.evp[k] = 0.0; o.cmeg[k] = 0.0; qds[k] = q[k]; o.md[k] = 0.0; o.ed[k] = 0.0; o.sd[k] = s[k];
+        o.qd[k] = q[k]; o.mc[k] = 0.0; o.qu[k] = q[k]; o.su[k] = s[k];
+        qsat_hPa(P, t[k], p[k], est, o.qst[k]);
+        if (p[k] - est <= 0.0) o.qst[k] = 1.0;
+        const double mrd = (1.0 + zvir * q[k]) * rd;
+        mcp[k] = (1.0 + cpvir * q[k]) * cp;
+        mrl[k] = (1.0 - dcol * (t[k] - tmelt)) * rl;
+        gamma[k] = o.qst[k] * (1.0 + o.qst[k] / eps1) * eps1 * mrl[k] / (mrd * (t[k] * t[k])) * mrl[k] / mcp[k];
+        hmn[k] = mcp[k] * t[k] + grav * z[k] + mrl[k] * q[k];
+        hsat[k] = mcp[k] * t[k] + grav * z[k] + mrl[k] * o.qst[k];
+        hu[k] = hmn[k];
+        hd[k] = hmn[k];
+        o.rprd[k] = 0.0;
+        o.qcde[k] = 0.0;
+        td[k] = (hd[k] - grav * zf[k] - (1.0 + dcol * tmelt) * rl * qds[k]) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * qds[k]));
+        tu[k] = 0.0;
+    }
+    for (int k = 1; k <= msg + 1; ++k) { hsthat[k] = hsat[k]; qsthat[k] = o.qst[k]; gamhat[k] = gamma[k]; }   // :3349-3355
+    totpcp = 0.0;
+    totevp = 0.0;
+    for (int k = msg + 2; k <= pver; ++k) {                                                  // :3360-3378
+        if (fabs(o.qst[k - 1] - o.qst[k]) > 1.E-6)
+            qsthat[k] = log(o.qst[k - 1] / o.qst[k]) * o.qst[k - 1] * o.qst[k] / (o.qst[k - 1] - o.qst[k]);
+        else
+            qsthat[k] = o.qst[k];
+        hsthat[k] = mcp[k] * shat[k] + mrl[k] * qsthat[k];
+        if (fabs(gamma[k - 1] - gamma[k]) > 1.E-6)
+            gamhat[k] = log(gamma[k - 1] / gamma[k]) * gamma[k - 1] * gamma[k] / (gamma[k - 1] - gamma[k]);
+        else
+            gamhat[k] = gamma[k];
+    }
+
+    o.jt = max(lel, P.limcnv + 1);                                                           // :3383-3390
+    o.jt = min(o.jt, pver);
+    o.jd = pver;
+    o.jlcl = lel;
+    hmin = 1.E6;
+    o.j0 = pver;
+    for (int k = msg + 1; k <= pver; ++k)                                                    // :3395-3402
+        if (hsat[k] <= hmin && k >= o.jt && k <= jb) { hmin = hsat[k]; o.j0 = k; }
+    o.j0 = min(o.j0, jb - 2);                                                                // :3404-3409
+    o.j0 = max(o.j0, o.jt + 2);
+    o.j0 = min(o.j0, pver);
+
+    for (int k = msg + 1; k <= pver; ++k) {                                                  // :3414-3424
+        if (k >= o.jt && k <= jb) {
+            hu[k] = hmn[mx] + cp * tiedke_msk;
+            o.su[k] = s[mx] + tiedke_msk / (1.0 + cpvir * o.qu[k]);
+        }
+    }
+    for (int k = pver - 1; k >= msg + 1; --k) {                                              // :3430-3442
+        if (k < jb && k >= o.jt) {
+            k1[k] = k1[k + 1] + (hmn[mx] - hmn[k]) * dz[k];
+            const double ihat = 0.5 * (k1[k + 1] + k1[k]);
+            i2[k] = i2[k + 1] + ihat * dz[k];
+            const double idag = 0.5 * (i2[k + 1] + i2[k]);
+            i3[k] = i3[k + 1] + idag * dz[k];
+            const double iprm = 0.5 * (i3[k + 1] + i3[k]);
+            i4[k] = i4[k + 1] + iprm * dz[k];
+        }
+    }
+    hmin = 1.E6;                                                                             // :3446-3456
+    for (int k = msg + 1; k <= pver; ++k) {
+        if (k >= o.j0 && k <= jb && hmn[k] <= hmin) {
+            hmin = hmn[k];
+            expdif = hmn[mx] - hmin;
+        }
+    }
+    for (int k = msg + 2; k <= pver; ++k) {                                                  // :3462-3487
+        expnum = 0.0;
+        ftemp = 0.0;
+        if (k < o.jt || k >= jb) {
+            k1[k] = 0.0;
+            expnum = 0.0;
+        } else {
+            expnum = hmn[mx] - (hsat[k - 1] * (zf[k] - z[k]) + hsat[k] * (z[k - 1] - zf[k])) / (z[k - 1] - z[k]);
+        }
+        if ((expdif > 100.0 && expnum > 0.0) && k1[k] > expnum * dz[k]) {
+            ftemp = expnum / k1[k];
+            const double ft2 = ftemp * ftemp, ft3 = ft2 * ftemp, ft4 = ft2 * ft2;
+            const double i2sq = i2[k] * i2[k], i2cu = i2sq * i2[k];
+            const double k1sq = k1[k] * k1[k], k1cu = k1sq * k1[k];
+            f[k] = ftemp + i2[k] / k1[k] * ft2 + (2.0 * i2sq - k1[k] * i3[k]) / k1sq * ft3
+                   + (-5.0 * k1[k] * i2[k] * i3[k] + 5.0 * i2cu + k1sq * i4[k]) / k1cu * ft4;
+            f[k] = fmax(f[k], 0.0);
+            f[k] = fmin(f[k], P.entrmn);
+        }
+    }
+    if (o.j0 < jb) {                                                                         // :3488-3492
+        if (f[o.j0] < 1.E-6 && f[o.j0 + 1] > f[o.j0]) o.j0 = o.j0 + 1;
+    }
+    for (int k = msg + 2; k <= pver; ++k)                                                    // :3493-3499
+        if (k >= o.jt && k <= o.j0) f[k] = fmax(f[k], f[k - 1]);
+    eps0 = f[o.j0];                                                                          // :3500-3503
+    eps[jb] = eps0;
+    for (int k = pver; k >= msg + 1; --k)                                                    // :3507-3518
+        if (k >= o.j0 && k <= jb) eps[k] = f[o.j0];
+    for (int k = pver; k >= msg + 1; --k)
+        if (k < o.j0 && k >= o.jt) eps[k] = f[k];
+
+    if (eps0 > 0.0) {                                                                        // :3550-3554
+        o.mu[jb] = 1.0;
+        o.eu[jb] = o.mu[jb] / dz[jb];
+    }
+    const int tmplel = o.jt;                                                                 // :3558
+    for (int k = pver; k >= msg + 1; --k) {                                                  // :3561-3571
+        if (eps0 > 0.0 && (k >= tmplel && k < jb)) {
+            zuef = zf[k] - zf[jb];
+            rmue = (1.0 / eps0) * (exp(eps[k + 1] * zuef) - 1.0) / zuef;
+            o.mu[k] = (1.0 / eps0) * (exp(eps[k] * zuef) - 1.0) / zuef;
+            o.eu[k] = (rmue - o.mu[k + 1]) / dz[k];
+            o.du[k] = (rmue - o.mu[k]) / dz[k];
+        }
+    }
+    for (int k = jb - 1; k >= lel; --k) {                                                    // :3579-3598
+        if (eps0 > 0.0) {
+            if (o.mu[k] < 0.02) {
+                hu[k] = hmn[k];
+                o.mu[k] = 0.0;
+                o.eu[k] = 0.0;
+                o.du[k] = o.mu[k + 1] / dz[k];
+            } else {
+                hu[k] = o.mu[k + 1] / o.mu[k] * hu[k + 1] + dz[k] / o.mu[k] * (o.eu[k] * hmn[k] - o.du[k] * hsat[k]);
+            }
+        }
+    }
+    bool doit = true;                                                                        // :3603-3628
+    for (int k = jb - 2; k >= lel - 1; --k) {
+        if (doit && k >= 1) {
+            if (hu[k] <= hsthat[k] && hu[k + 1] > hsthat[k + 1] && o.mu[k] >= 0.02) {
+                if (hu[k] - hsthat[k] < -2000.0) { o.jt = k + 1; doit = false; }
+                else { o.jt = k; doit = false; }
+            } else if ((hu[k] > hu[jb]) || o.mu[k] < 0.02) {           // totfrz == 0 without microphysics
+                o.jt = k + 1;
+                doit = false;
+            }
+        }
+    }
+    for (int k = pver; k >= msg + 1; --k) {                                                  // :3632-3646
+        if (k >= lel && k <= o.jt && eps0 > 0.0) { o.mu[k] = 0.0; o.eu[k] = 0.0; o.du[k] = 0.0; hu[k] = hmn[k]; }
+        if (k == o.jt && eps0 > 0.0) {
+            o.du[k] = o.mu[k + 1] / dz[k];
+            o.eu[k] = 0.0;
+            o.mu[k] = 0.0;
+        }
+    }
+    for (int k = pver; k >= msg + 2; --k)                                                    // :3649-3654
+        tu[k] = (hu[k] - grav * zf[k] - (1.0 + dcol * tmelt) * rl * o.qu[k]) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * o.qu[k]));
+
+    for (int k = pver; k >= msg + 2; --k) {                                                  // :3656-3692
+        if (k == jb && eps0 > 0.0) {
+            o.qu[k] = q[mx];
+            tu[k] = (hu[k] - grav * zf[k] - (1.0 + dcol * tmelt) * rl * o.qu[k]) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * o.qu[k]));
+            o.su[k] = (hu[k] - (1.0 - dcol * (tu[k] - tmelt)) * rl * o.qu[k]) / ((1.0 + cpvir * o.qu[k]) * cp);
+        }
+        if ((k > o.jt && k < jb) && eps0 > 0.0) {
+            o.su[k] = o.mu[k + 1] / o.mu[k] * o.su[k + 1] + dz[k] / o.mu[k] * (o.eu[k] - o.du[k]) * s[k];
+            o.qu[k] = o.mu[k + 1] / o.mu[k] * o.qu[k + 1] + dz[k] / o.mu[k] * (o.eu[k] * q[k] - o.du[k] * o.qst[k]);
+            // 0.85 is a default-REAL literal in the reference (:3680): single precision, then promoted
+            tu[k] = o.su[k] - grav / ((1.0 + (double)0.85f * o.qu[k]) * cp) * zf[k];
+            qsat_hPa(P, tu[k], (p[k] + p[k - 1]) / 2.0, estu, qstu);
+            if (o.qu[k] >= qstu) {
+                o.jlcl = k;
+                break;                                                                       // :3690
+            }
+        }
+    }
+    for (int k = msg + 2; k <= pver; ++k) {                                                  // :3693-3707
+        if ((k > o.jt && k <= o.jlcl) && eps0 > 0.0) {
+            o.qu[k] = qsthat[k] + gamhat[k] * (hu[k] - hsthat[k]) / ((1.0 - dcol * (tu[k] - tmelt)) * rl * (1.0 + gamhat[k]));
+            o.su[k] = shat[k] + (hu[k] - hsthat[k]) / ((1.0 + cpvir * o.qu[k]) * cp * (1.0 + gamhat[k]));
+            tu[k] = o.su[k] - grav / ((1.0 + cpvir * o.qu[k]) * cp) * zf[k];
+        }
+    }
+    for (int k = pver; k >= msg + 2; --k) {                                                  // :3716-3739
+        if (k >= o.jt && k < jb && eps0 > 0.0) {
+            o.cu[k] = ((o.mu[k] * o.su[k] - o.mu[k + 1] * o.su[k + 1]) / dz[k] - (o.eu[k] - o.du[k]) * s[k]) / (rl / cp)
+                      * ((1.0 + cpvir * o.qu[k]) / (1.0 - dcol * (tu[k] - tmelt)));
+            if (k == o.jt) o.cu[k] = 0.0;
+            o.cu[k] = fmax(0.0, o.cu[k]);
+        }
+    }
+    for (int k = pver; k >= msg + 2; --k) {                                                  // :3846-3870
+        o.rprd[k] = 0.0;
+        if (k >= o.jt && k < jb && eps0 > 0.0 && o.mu[k] >= 0.0) {
+            if (o.mu[k] > 0.0) {
+                ql1 = 1.0 / o.mu[k] * (o.mu[k + 1] * o.ql[k + 1] - dz[k] * o.du[k] * o.ql[k + 1] + dz[k] * o.cu[k]);
+                o.ql[k] = ql1 / (1.0 + dz[k] * c0mask);
+            } else {
+                o.ql[k] = 0.0;
+            }
+            totpcp = totpcp + dz[k] * (o.cu[k] - o.du[k] * o.ql[k + 1]);
+            o.rprd[k] = c0mask * o.mu[k] * o.ql[k];
+            o.qcde[k] = o.ql[k];
+        }
+    }
+
+    // downdraft :3880-3975
+    const double alfa = P.alfadet;
+    o.jt = min(o.jt, jb - 1);
+    o.jd = max(o.j0, o.jt + 1);
+    o.jd = min(o.jd, jb);
+    hd[o.jd] = hmn[o.jd - 1];
+    if (o.jd < jb && eps0 > 0.0) {
+        epsm = eps0;
+        o.md[o.jd] = -alfa * epsm / eps0;
+    }
+    for (int k = msg + 1; k <= pver; ++k) {                                                  // :3896-3904
+        if ((k > o.jd && k <= jb) && eps0 > 0.0) {
+            zdef = zf[o.jd] - zf[k];
+            o.md[k] = -alfa / (2.0 * eps0) * (exp(2.0 * epsm * zdef) - 1.0) / zdef;
+        }
+    }
+    for (int k = msg + 1; k <= pver; ++k) {                                                  // :3906-3913
+        if ((k >= o.jt && k <= jb) && eps0 > 0.0 && o.jd < jb) {
+            ratmjb = fmin(fabs(o.mu[jb] / o.md[jb]), 1.0);
+            o.md[k] = o.md[k] * ratmjb;
+        }
+    }
+    for (int k = msg + 1; k <= pver; ++k) {                                                  // :3916-3924
+        if ((k >= o.jt && k <= pver) && eps0 > 0.0) {
+            o.ed[k - 1] = (o.md[k - 1] - o.md[k]) / dz[k - 1];
+            mdt = fmin(o.md[k], -small);
+            hd[k] = (o.md[k - 1] * hd[k - 1] - dz[k - 1] * o.ed[k - 1] * hmn[k - 1]) / mdt;
+        }
+    }
+    for (int k = msg + 2; k <= pver; ++k) {                                                  // :3928-3941
+        if ((k >= o.jd && k <= jb) && eps0 > 0.0 && o.jd < jb) {
+            qds[k] = qsthat[k] + gamhat[k] * (hd[k] - hsthat[k]) / (rl * (1.0 + gamhat[k]));
+            td[k] = (hd[k] - grav * zf[k] - (1.0 + dcol * tmelt) * rl * qds[k]) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * qds[k]));
+            qds[k] = qsthat[k] + gamhat[k] * (hd[k] - hsthat[k]) / ((1.0 - dcol * (td[k] - tmelt)) * rl * (1.0 + gamhat[k]));
+        }
+    }
+    {                                                                                        // :3943-3951
+        const int k = o.jd;
+        o.qd[k] = qds[k];
+        o.sd[k] = (hd[k] - (1.0 - dcol * (td[k] - tmelt)) * rl * o.qd[k]) / ((1.0 + cpvir * o.qd[k]) * cp);
+        td[k] = o.sd[k] - grav / ((1.0 + cpvir * o.qd[k]) * cp) * zf[k];
+    }
+    for (int k = msg + 2; k <= pver; ++k) {                                                  // :3953-3971
+        if (k >= o.jd && k < jb && eps0 > 0.0) {
+            o.qd[k + 1] = qds[k + 1];
+            o.evp[k] = -o.ed[k] * q[k] + (o.md[k] * o.qd[k] - o.md[k + 1] * o.qd[k + 1]) / dz[k];
+            o.evp[k] = fmax(o.evp[k], 0.0);
+            mdt = fmin(o.md[k + 1], -small);
+            o.sd[k + 1] = (((1.0 - dcol * (td[k] - tmelt)) * rl / ((1.0 + cpvir * o.qd[k]) * cp) * o.evp[k] - o.ed[k] * s[k]) * dz[k]
+                           + o.md[k] * o.sd[k]) / mdt;
+            totevp = totevp - dz[k] * o.ed[k] * q[k];
+        }
+    }
+    totevp = totevp + o.md[o.jd] * o.qd[o.jd] - o.md[jb] * o.qd[jb];                         // :3974
+    totpcp = fmax(totpcp, 0.0);
+    totevp = fmax(totevp, 0.0);
+    for (int k = msg + 2; k <= pver; ++k) {                                                  // :3993-4009
+        if (totevp > 0.0 && totpcp > 0.0) {
+            o.md[k] = o.md[k] * fmin(1.0, totpcp / (totevp + totpcp));
+            o.ed[k] = o.ed[k] * fmin(1.0, totpcp / (totevp + totpcp));
+            o.evp[k] = o.evp[k] * fmin(1.0, totpcp / (totevp + totpcp));
+        } else {
+            o.md[k] = 0.0; o.ed[k] = 0.0; o.evp[k] = 0.0;
+        }
+        o.cmeg[k] = o.cu[k] - o.evp[k];
+        o.rprd[k] = o.rprd[k] - o.evp[k];
+    }
+    o.pflx[1] = 0.0;                                                                         // :4012-4017
+    for (int k = 2; k <= pver + 1; ++k) o.pflx[k] = o.pflx[k - 1] + o.rprd[k - 1] * dz[k - 1];
+    for (int k = msg + 1; k <= pver; ++k) o.mc[k] = o.mu[k] + o.md[k];
+}
+
+// closure :4028-4260
+template <int ML>
+__device__ double closure_d(const ZmDev &P, int pver, int msg, const double *q, const double *t, const double *p,
+                            const double *s, const double *tp, const CldOut<ML> &cl, const double *qhat,
+                            const double *shat, const double *dp, const double *qstp, const double *zf, double dsubcld,
+                            double cape, double tl, int lcl, int lel, int jt, int mx)
+{
+    const double rd = P.rgas, cp = P.cp, rl = P.rl, eps1 = P.eps1, grav = P.grav;
+    const double *mu = cl.mu, *md = cl.md, *su = cl.su, *sd = cl.sd, *qu = cl.qu, *qd = cl.qd, *mc = cl.mc, *du = cl.du,
+                 *ql = cl.ql;
+    double mb = 0.0;
+    const double eb = p[mx] * q[mx] / (eps1 + q[mx]);
+    const double dtbdt = (1.0 / dsubcld) * (mu[mx] * (shat[mx] - su[mx]) + md[mx] * (shat[mx] - sd[mx]));
+    const double dqbdt = (1.0 / dsubcld) * (mu[mx] * (qhat[mx] - qu[mx]) + md[mx] * (qhat[mx] - qd[mx]));
+    const double debdt = eps1 * p[mx] / ((eps1 + q[mx]) * (eps1 + q[mx])) * dqbdt;
+    const double lg = (3.5 * log(t[mx]) - log(eb) - 4.805);
+    const double dtldt = -2840.0 * (3.5 / t[mx] * dtbdt - debdt / eb) / (lg * lg);
+    const double beta = 0.0;
+
+    double dadt = 0.0;
+    for (int k = lel; k <= mx - 1; ++k) {
+        double dtmdt = 0.0, dqmdt = 0.0, dboydt;
+        if (k == jt && k <= pver - 1) {                                                      // :4154-4169
+            dqmdt = (1.0 / dp[k]) * (mu[k + 1] * (qu[k + 1] - qhat[k + 1] + ql[k + 1]) + md[k + 1] * (qd[k + 1] - qhat[k + 1]));
+            dtmdt = (1.0 / dp[k]) * (mu[k + 1] * (su[k + 1] - shat[k + 1] - rl / cp * ql[k + 1]) + md[k + 1] * (sd[k + 1] - shat[k + 1]));
+        }
+        if (k > jt && k < mx) {                                                              // :4172-4189
+            dtmdt = (mc[k] * (shat[k] - s[k]) - mc[k + 1] * (shat[k + 1] - s[k])) / dp[k]
+                    - rl / cp * du[k] * (beta * ql[k] + (1 - beta) * ql[k + 1]);
+            dqmdt = (mu[k + 1] * (qu[k + 1] - qhat[k + 1] + cp / rl * (su[k + 1] - s[k]))
+                     - mu[k] * (qu[k] - qhat[k] + cp / rl * (su[k] - s[k]))
+                     + md[k + 1] * (qd[k + 1] - qhat[k + 1] + cp / rl * (sd[k + 1] - s[k]))
+                     - md[k] * (qd[k] - qhat[k] + cp / rl * (sd[k] - s[k]))) / dp[k]
+                    + du[k] * (beta * ql[k] + (1 - beta) * ql[k + 1]);
+        }
+        if (k <= lcl) {                                                                      // :4191-4222
+            const double thetavp = tp[k] * pow(1000.0 / p[k], rd / cp) * (1.0 + 1.608 * qstp[k] - q[mx]);
+            const double thetavm = t[k] * pow(1000.0 / p[k], rd / cp) * (1.0 + 0.608 * q[k]);
+            const double dqsdtp = qstp[k] * (1.0 + qstp[k] / eps1) * eps1 * rl / (rd * (tp[k] * tp[k]));
+            const double dtpdt = tp[k] / (1.0 + rl / cp * (dqsdtp - qstp[k] / tp[k]))
+                                 * (dtbdt / t[mx] + rl / cp * (dqbdt / tl - q[mx] / (tl * tl) * dtldt));
+            dboydt = ((dtpdt / tp[k] + 1.0 / (1.0 + 1.608 * qstp[k] - q[mx]) * (1.608 * dqsdtp * dtpdt - dqbdt))
+                      - (dtmdt / t[k] + 0.608 / (1.0 + 0.608 * q[k]) * dqmdt)) * grav * thetavp / thetavm;
+        } else {                                                                             // :4224-4239
+            const double thetavp = tp[k] * pow(1000.0 / p[k], rd / cp) * (1.0 + 0.608 * q[mx]);
+            const double thetavm = t[k] * pow(1000.0 / p[k], rd / cp) * (1.0 + 0.608 * q[k]);
+            dboydt = (dtbdt / t[mx] + 0.608 / (1.0 + 0.608 * q[mx]) * dqbdt - dtmdt / t[k]
+                      - 0.608 / (1.0 + 0.608 * q[k]) * dqmdt) * grav * thetavp / thetavm;
+        }
+        dadt = dadt + dboydt * (zf[k] - zf[k + 1]);                                          // :4247-4253
+    }
+    const double dltaa = -1.0 * (cape - P.capelmt);
+    if (dadt != 0.0) mb = fmax(dltaa / P.tau / dadt, 0.0);
+    return mb;
+}
+
+__device__ void interface_values_d(int pver, int msg, const double *sg, const double *qg, double *shat, double *qhat)
+{   // :1007-1027
+    for (int k = msg + 2; k <= pver; ++k) {
+        double sdifr = 0.0, qdifr = 0.0;
+        if (sg[k] > 0.0 || sg[k - 1] > 0.0) sdifr = fabs((sg[k] - sg[k - 1]) / fmax(sg[k - 1], sg[k]));
+        if (qg[k] > 0.0 || qg[k - 1] > 0.0) qdifr = fabs((qg[k] - qg[k - 1]) / fmax(qg[k - 1], qg[k]));
+        if (sdifr > 1.E-6) shat[k] = log(sg[k - 1] / sg[k]) * sg[k - 1] * sg[k] / (sg[k - 1] - sg[k]);
+        else shat[k] = 0.5 * (sg[k] + sg[k - 1]);
+        if (qdifr > 1.E-6) qhat[k] = log(qg[k - 1] / qg[k]) * qg[k - 1] * qg[k] / (qg[k - 1] - qg[k]);
+        else qhat[k] = 0.5 * (qg[k] + qg[k - 1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Kernel 2: plume ensemble, second ascent, closure, tendencies -- first-pass triggered columns only
+// ------------------------------------------------------------------------------------------------------
+template <int ML>
+__global__ __launch_bounds__(WAVE) void zm_plume_kernel(ZmDev P, int ncol, int pver, double delt, colphys_zm_convr_io io,
+                                                       ZmWorkspace ws)
+{
+    extern __shared__ double smem[];            // [(pver+2)][WAVE]
+    const int lane = threadIdx.x;
+    const int gid = blockIdx.x * WAVE + lane;
+    const int count = *ws.count;
+    if (gid >= count) return;
+    const int col = ws.list[gid];
+    const int msg = P.limcnv - 1;
+    const size_t L = (size_t)pver, LP = (size_t)pver + 1;
+
+    const ColIn c = make_colin(P, io, col, pver);
+    double q[ML], t[ML], p[ML], z[ML], s[ML], zf[ML], shat[ML], qhat[ML], dp[ML], tp[ML], qstp[ML];
+    CldOut<ML> cl;
+
+    zf[pver + 1] = c.Zf(pver + 1);
+    for (int k = 1; k <= pver; ++k) {                                                        // :825-860, 926-940
+        q[k] = c.Q(k); t[k] = c.T(k); p[k] = c.Pm(k); z[k] = c.Z(k); zf[k] = c.Zf(k);
+        s[k] = t[k] + (P.grav / ((1.0 + P.zvir * q[k]) * P.cpres)) * z[k];
+        shat[k] = s[k]; qhat[k] = q[k];
+        dp[k] = 0.01 * c.dpp[k];
+    }
+    const double pblt = pbl_top_index(c);
+
+    int maxg = ws.mx1[col], lelg = ws.lel1[col];
+    double dsubcld = 0.0;
+    for (int k = msg + 1; k <= pver; ++k)                                                    // :995-1001
+        if (k >= maxg) dsubcld = dsubcld + dp[k];
+    interface_values_d(pver, msg, s, q, shat, qhat);
+
+    cldprp_d<ML>(P, pver, msg, q, t, p, z, s, zf, shat, qhat, maxg, lelg, c.landfrac, cl);   // :1032
+
+    double dmpdz = -1.0;                                                                     // :1046-1078
+    {
+        double hk = 0.0, dmmx = 0.0, dmsm = 0.0;
+        const double orgc = 1.0;
+        for (int k = pver; k >= msg + 1; --k) {
+            if (cl.eu[k] > 0) {
+                dmmx = -fmax(-dmmx, cl.eu[k]);
+                dmsm = dmsm - cl.eu[k];
+                hk = hk + 1.0;
+            }
+        }
+        if (hk > 0) {
+            dmsm = dmsm / hk;
+            dmpdz = dmsm * orgc + dmmx * (1.0 - orgc);
+        }
+    }
+    BuoyRes r;
+    buoyan_dilute_d<true>(P, c, pblt, dmpdz, ws.cin1[col], smem + lane, tp, qstp, r);        // :1080
+    io.cape[col] = r.cape;
+    io.status[col] |= r.status;
+    if (!(r.cape > P.capelmt && r.cin < r.cape * P.cin_threshd)) return;                     // :1099-1107
+
+    maxg = r.mx; lelg = r.lel;                                                               // :1156-1195
+    dsubcld = 0.0;
+    for (int k = msg + 1; k <= pver; ++k)
+        if (k >= maxg) dsubcld = dsubcld + dp[k];
+    // shat/qhat depend only on s, q: unchanged (:1175-1195 recompute the same values)
+
+    cldprp_d<ML>(P, pver, msg, q, t, p, z, s, zf, shat, qhat, maxg, lelg, c.landfrac, cl);   // :1216
+
+    for (int k = msg + 1; k <= pver; ++k) {                                                  // :1252-1262
+        const double dzk = (zf[k] - zf[k + 1]);
+        cl.du[k] = cl.du[k] * dzk / dp[k];   cl.eu[k] = cl.eu[k] * dzk / dp[k];   cl.ed[k] = cl.ed[k] * dzk / dp[k];
+        cl.cu[k] = cl.cu[k] * dzk / dp[k];   cl.cmeg[k] = cl.cmeg[k] * dzk / dp[k]; cl.rprd[k] = cl.rprd[k] * dzk / dp[k];
+        cl.evp[k] = cl.evp[k] * dzk / dp[k];
+    }
+
+    double mb = closure_d<ML>(P, pver, msg, q, t, p, s, tp, cl, qhat, shat, dp, qstp, zf, dsubcld, r.cape, r.tl, r.lcl,
+                              lelg, cl.jt, maxg);                                            // :1273
+    double mumax = 0;                                                                        // :1285-1300
+    for (int k = msg + 2; k <= pver; ++k) mumax = fmax(mumax, cl.mu[k] / dp[k]);
+    if (mumax > 0.0) mb = fmin(mb, 0.5 / (delt * mumax));
+    else mb = 0.0;
+    if (P.no_deep_pbl) {                                                                     // :1304-1308
+        if (c.zm[cl.jt] < c.pblh) mb = 0;
+    }
+    for (int k = msg + 1; k <= pver; ++k) {                                                  // :1319-1331
+        cl.mu[k] = cl.mu[k] * mb; cl.md[k] = cl.md[k] * mb; cl.mc[k] = cl.mc[k] * mb; cl.du[k] = cl.du[k] * mb;
+        cl.eu[k] = cl.eu[k] * mb; cl.ed[k] = cl.ed[k] * mb; cl.cmeg[k] = cl.cmeg[k] * mb; cl.rprd[k] = cl.rprd[k] * mb;
+        cl.cu[k] = cl.cu[k] * mb; cl.evp[k] = cl.evp[k] * mb;
+        cl.pflx[k + 1] = cl.pflx[k + 1] * mb * 100.0 / P.grav;
+    }
+
+    // q1q2_pjr :4262-4421 fused with the scatter :1495-1511 and the integrals :1629-1649
+    double *o_qtnd = io.qtnd + col * L - 1, *o_heat = io.heat + col * L - 1, *o_cme = io.cme + col * L - 1,
+           *o_zdu = io.zdu + col * L - 1, *o_rprd = io.rprd + col * L - 1, *o_dlf = io.dlf + col * L - 1,
+           *o_ql = io.ql + col * L - 1, *o_eurt = io.eurt + col * L - 1, *o_mcon = io.mcon + col * LP - 1,
+           *o_pflx = io.pflx + col * LP - 1;
+    const double rl = P.rl, cp = P.cp;
+    const int jt = cl.jt, mx = maxg;
+    double dsdt_km1 = 0.0, dqdt_km1 = 0.0;
+    double *dqdt = tp, *dlg = qstp;            // reuse private profiles
+    for (int k = msg + 1; k <= pver; ++k) {
+        double dsdt = 0.0, dq = 0.0, dl = 0.0;
+        if (k >= jt && k <= pver - 1) {                                                      // :4364-4399
+            const double emc = -cl.cu[k] + cl.evp[k];
+            dsdt = -rl / cp * emc + (cl.mu[k + 1] * (cl.su[k + 1] - shat[k + 1]) - cl.mu[k] * (cl.su[k] - shat[k])
+                                     + cl.md[k + 1] * (cl.sd[k + 1] - shat[k + 1]) - cl.md[k] * (cl.sd[k] - shat[k])) / dp[k];
+            dq = emc + (cl.mu[k + 1] * (cl.qu[k + 1] - qhat[k + 1]) - cl.mu[k] * (cl.qu[k] - qhat[k])
+                        + cl.md[k + 1] * (cl.qd[k + 1] - qhat[k + 1]) - cl.md[k] * (cl.qd[k] - qhat[k])) / dp[k];
+            dl = cl.du[k] * cl.qcde[k + 1];
+        }
+        if (k == mx) {                                                                       // :4402-4418
+            dsdt = (1.0 / dsubcld) * (-cl.mu[k] * (cl.su[k] - shat[k]) - cl.md[k] * (cl.sd[k] - shat[k]));
+            dq = (1.0 / dsubcld) * (-cl.mu[k] * (cl.qu[k] - qhat[k]) - cl.md[k] * (cl.qd[k] - qhat[k]));
+        } else if (k > mx) {
+            dsdt = dsdt_km1;
+            dq = dqdt_km1;
+        }
+        dsdt_km1 = dsdt; dqdt_km1 = dq;
+        dqdt[k] = dq; dlg[k] = dl;
+        o_qtnd[k] = dq;                                                                      // :1495-1511
+        o_cme[k] = cl.cmeg[k];
+        o_rprd[k] = cl.rprd[k];
+        o_zdu[k] = cl.du[k];
+        o_mcon[k] = cl.mc[k];
+        o_heat[k] = dsdt * P.cpres;
+        o_dlf[k] = dl;
+        o_pflx[k] = cl.pflx[k];
+        o_ql[k] = cl.ql[k];
+        o_eurt[k] = -dmpdz;                                                                  // :1233-1237
+    }
+    io.jctop[col] = jt;                                                                      // :1616-1620
+    io.jcbot[col] = maxg;
+    o_pflx[pver + 1] = cl.pflx[pver + 1];
+
+    double prec = 0.0, rliq = 0.0;
+    for (int k = pver; k >= msg + 1; --k) {                                                  // :1629-1633 (dif == 0)
+        const double qnew = q[k] + 2.0 * delt * dqdt[k];
+        prec = prec - c.dpp[k] * (qnew - q[k]) - c.dpp[k] * (dlg[k] + 0.0) * 2.0 * delt;
+    }
+    prec = P.rgrav * fmax(prec, 0.0) / (2.0 * delt) / 1000.0;                                // :1637
+    for (int k = 1; k <= pver; ++k) {                                                        // :1642-1649
+        const double dlfk = (k >= msg + 1) ? dlg[k] : 0.0;
+        rliq = rliq + (dlfk + 0.0) * c.dpp[k] / P.gravit;
+    }
+    io.prec[col] = prec;
+    io.rliq[col] = rliq / 1000.0;
+    io.rice[col] = 0.0 / 1000.0;
+
+    // full-layout plume profiles; zm_gather_kernel compacts them per chunk
+    double *w_mu = ws.mu_f + col * L - 1, *w_md = ws.md_f + col * L - 1, *w_du = ws.du_f + col * L - 1,
+           *w_eu = ws.eu_f + col * L - 1, *w_ed = ws.ed_f + col * L - 1, *w_dp = ws.dp_f + col * L - 1;
+    for (int k = 1; k <= pver; ++k) {
+        w_mu[k] = cl.mu[k]; w_md[k] = cl.md[k]; w_du[k] = cl.du[k]; w_eu[k] = cl.eu[k]; w_ed[k] = cl.ed[k]; w_dp[k] = dp[k];
+    }
+    ws.dsub_f[col] = dsubcld;
+    ws.jt_f[col] = jt;
+    ws.maxg_f[col] = maxg;
+    ws.deep[col] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Kernel 3: per-chunk ascending compaction into the reference's gathered layout
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void zm_gather_kernel(int ncol, int pver, int pcols, colphys_zm_convr_io io, ZmWorkspace ws)
+{
+    __shared__ int s_src[1024];
+    __shared__ int s_n;
+    const int c0 = blockIdx.x * pcols;
+    const int nc = min(pcols, ncol - c0);
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int i = 0; i < nc; ++i)
+            if (ws.deep[c0 + i]) { s_src[n] = i; ++n; }
+        s_n = n;
+        io.lengath[blockIdx.x] = n;
+    }
+    __syncthreads();
+    const int n = s_n;
+    const size_t L = (size_t)pver;
+    for (int j = 0; j < n; ++j) {
+        const size_t src = (size_t)(c0 + s_src[j]) * L, dst = (size_t)(c0 + j) * L;
+        for (int k = threadIdx.x; k < pver; k += blockDim.x) {
+            io.mu[dst + k] = ws.mu_f[src + k]; io.md[dst + k] = ws.md_f[src + k]; io.du[dst + k] = ws.du_f[src + k];
+            io.eu[dst + k] = ws.eu_f[src + k]; io.ed[dst + k] = ws.ed_f[src + k]; io.dp[dst + k] = ws.dp_f[src + k];
+        }
+    }
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const int src = c0 + s_src[j];
+        io.dsubcld[c0 + j] = ws.dsub_f[src];
+        io.jt[c0 + j] = ws.jt_f[src];
+        io.maxg[c0 + j] = ws.maxg_f[src];
+        io.ideep[c0 + j] = s_src[j] + 1;
+    }
+}
+
+}  // namespace
+
+int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io &io,
+                    const ZmWorkspace &ws, hipStream_t st, hipEvent_t *ev)
+{
+    if (pcols > 1024) return COLPHYS_ERR_ARG;
+    const int nblk = (ncol + WAVE - 1) / WAVE;
+    const size_t lds = (size_t)(pver + 2) * WAVE * sizeof(double);
+    const int nchunks = (ncol + pcols - 1) / pcols;
+    if (hipMemsetAsync(ws.count, 0, sizeof(int), st) != hipSuccess) return COLPHYS_ERR_HIP;
+    if (ev) hipEventRecord(ev[0], st);
+    hipLaunchKernelGGL(zm_trigger_kernel, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, io, ws);
+    if (ev) { hipEventRecord(ev[1], st); hipEventRecord(ev[2], st); }
+    if (pver <= 32)
+        hipLaunchKernelGGL(zm_plume_kernel<36>, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, delt, io, ws);
+    else if (pver <= 72)
+        hipLaunchKernelGGL(zm_plume_kernel<76>, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, delt, io, ws);
+    else
+        hipLaunchKernelGGL(zm_plume_kernel<COLPHYS_MAX_PVER + 4>, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, delt, io, ws);
+    hipLaunchKernelGGL(zm_gather_kernel, dim3(nchunks), dim3(WAVE), 0, st, ncol, pver, pcols, io, ws);
+    if (ev) hipEventRecord(ev[3], st);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}

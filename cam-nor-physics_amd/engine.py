@@ -1,0 +1,241 @@
+"""Host-side mirror of the reference's operator surface for the hot path, over the C ABI (include/colphys.h).
+
+    reference (Fortran)                                      here
+    -------------------------------------------------------  ---------------------------------
+    zm_convi            physics/zm_conv.F90:115              ColumnPhysics(params, device)
+    geopotential_t      physics/geopotential.F90:153         ColumnPhysics.geopotential_t
+    zm_convr            physics/zm_conv.F90:231              ColumnPhysics.zm_convr
+    zm_conv_evap        physics/zm_conv.F90:1712             ColumnPhysics.zm_conv_evap
+    momtran             physics/zm_conv.F90:2315             ColumnPhysics.momtran
+    modal_aero_sw / lw  physics/modal_aer_opt.F90:485,1216   ColumnPhysics.modal_aero_sw / _lw
+
+Same argument names and meaning as the Fortran dummies; arrays are torch CUDA tensors in the
+column-contiguous device layout ([ncol][pver], interfaces [ncol][pver+1]).  torch is plumbing only:
+device memory and the current stream.  There is NO fallback: if libcolphys_hip.so is missing or no
+GPU is present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .build import LIB, build_hip
+
+_lib = None
+
+
+class ColphysError(RuntimeError):
+    pass
+
+
+def load_library(build_if_missing: bool = False) -> C.CDLL:
+    """Loads the HIP extension; fails loudly when it is absent (no CPU path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        if build_if_missing:
+            build_hip()
+        else:
+            raise ColphysError(f"{LIB} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(LIB)
+    lib.colphys_last_error.restype = C.c_char_p
+    lib.colphys_init.argtypes = [C.c_int, C.POINTER(abi.ZmParams)]
+    lib.colphys_profile_get.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "colphys_abi_version", "colphys_last_error", "colphys_device_count", "colphys_zm_params_defaults",
+    "colphys_init", "colphys_finalize",
+    "colphys_geopotential_t_dev", "colphys_geopotential_t_chunks",
+    "colphys_zm_convr_dev", "colphys_zm_convr_chunks",
+    "colphys_zm_conv_evap_dev", "colphys_zm_conv_evap_chunks",
+    "colphys_momtran_dev", "colphys_momtran_chunks",
+    "colphys_aero_tables_set",
+    "colphys_modal_aero_sw_dev", "colphys_modal_aero_lw_dev",
+    "colphys_modal_aero_sw_chunks", "colphys_modal_aero_lw_chunks",
+    "colphys_profile_enable", "colphys_profile_reset", "colphys_profile_get",
+]
+
+
+def _p(t, ctype=abi.PD):
+    return C.cast(C.c_void_p(t.data_ptr()), ctype)
+
+
+class ColumnPhysics:
+    def __init__(self, params: abi.ZmParams, device: int = 0):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise ColphysError("no HIP device visible: the engine has no CPU path")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.params = params
+        self._check(self.lib.colphys_init(device, C.byref(params)))
+        self._keep = []
+        self.tables = None
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            raise ColphysError(f"colphys error {rc}: {self.lib.colphys_last_error().decode()}")
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def dev(self, a, dtype=None):
+        """numpy / tensor -> contiguous CUDA tensor (fp64 unless int32 requested)"""
+        t = self.torch
+        if isinstance(a, np.ndarray):
+            a = t.from_numpy(np.ascontiguousarray(a))
+        if dtype is None:
+            dtype = t.int32 if a.dtype in (t.int32, t.int64) else t.float64
+        return a.to(device=self.device, dtype=dtype).contiguous()
+
+    def _f64(self, x):
+        assert x.is_cuda and x.dtype == self.torch.float64 and x.is_contiguous(), (x.dtype, x.device)
+        return x
+
+    def empty(self, *shape, dtype=None):
+        return self.torch.empty(*shape, dtype=dtype or self.torch.float64, device=self.device)
+
+    def close(self):
+        self.lib.colphys_finalize()
+
+    # ---- geopotential_t (geopotential.F90:153) ----------------------------------------------------
+    def geopotential_t(self, piln, pmln, pint, pmid, pdel, rpdel, t, q, rair, gravit, zvir, zi=None, zm=None,
+                       dycore=abi.DYCORE_FV, nspecies=1):
+        """q: [ncol][pver] (water vapour) or [nq][ncol][pver]."""
+        n, pver = t.shape
+        nq = 1 if q.dim() == 2 else q.shape[0]
+        zi = self.empty(n, pver + 1) if zi is None else zi
+        zm = self.empty(n, pver) if zm is None else zm
+
+        def opt(x):
+            return _p(self._f64(x)) if x is not None else None
+        self._check(self.lib.colphys_geopotential_t_dev(
+            C.c_int(n), C.c_int(pver), C.c_int(dycore), C.c_int(nq), C.c_int(nspecies), opt(piln), opt(pmln), opt(pint),
+            opt(pmid), opt(pdel), opt(rpdel), opt(t), opt(q), opt(rair), C.c_double(gravit), opt(zvir), _p(zi), _p(zm),
+            self._stream()))
+        return zi, zm
+
+    # ---- zm_convr (zm_conv.F90:231) ----------------------------------------------------------------
+    def alloc_zm_convr_out(self, n, pver, pcols):
+        t = self.torch
+        o = {}
+        for k in abi.ZM_CONVR_OUT_MID:
+            o[k] = self.empty(n, pver)
+        for k in abi.ZM_CONVR_OUT_INT:
+            o[k] = self.empty(n, pver + 1)
+        for k in abi.ZM_CONVR_OUT_COL:
+            o[k] = self.empty(n)
+        for k in abi.ZM_CONVR_OUT_ICOL:
+            o[k] = self.empty(n, dtype=t.int32)
+        o["lengath"] = self.empty((n + pcols - 1) // pcols, dtype=t.int32)
+        return o
+
+    def zm_convr(self, t, qh, pblh, zm, geos, zi, pap, paph, dpp, delt, tpert, landfrac, pcols=16, out=None):
+        n, pver = t.shape
+        o = self.alloc_zm_convr_out(n, pver, pcols) if out is None else out
+        io = abi.ZmConvrIO()
+        ins = dict(t=t, qh=qh, pap=pap, dpp=dpp, zm=zm, paph=paph, zi=zi, geos=geos, pblh=pblh, tpert=tpert, landfrac=landfrac)
+        for k, v in ins.items():
+            setattr(io, k, _p(self._f64(v)))
+        for k, v in o.items():
+            setattr(io, k, _p(v, abi.PI) if v.dtype == self.torch.int32 else _p(v))
+        self._check(self.lib.colphys_zm_convr_dev(C.c_int(n), C.c_int(pver), C.c_int(pcols), C.c_double(delt), C.byref(io),
+                                                  self._stream()))
+        return o
+
+    # ---- zm_conv_evap (zm_conv.F90:1712) -----------------------------------------------------------
+    def zm_conv_evap(self, t, pmid, pdel, q, landfrac, prdprec, cldfrc, deltat, prec, out=None):
+        """prec is updated in place (m/s in, m/s out) exactly like the reference's intent(inout) dummy."""
+        n, pver = t.shape
+        if out is None:
+            out = {k: self.empty(n, pver) for k in abi.EVAP_OUT_MID}
+            out.update({k: self.empty(n, pver + 1) for k in abi.EVAP_OUT_INT})
+            out["snow"] = self.empty(n)
+        io = abi.ZmConvEvapIO()
+        ins = dict(t=t, pmid=pmid, pdel=pdel, q=q, prdprec=prdprec, cldfrc=cldfrc, landfrac=landfrac, prec=prec)
+        for k, v in {**ins, **out}.items():
+            setattr(io, k, _p(self._f64(v)))
+        self._check(self.lib.colphys_zm_conv_evap_dev(C.c_int(n), C.c_int(pver), C.c_double(deltat), C.byref(io), self._stream()))
+        out["prec"] = prec
+        return out
+
+    # ---- momtran (zm_conv.F90:2315) ----------------------------------------------------------------
+    def momtran(self, winds, mu, md, du, eu, ed, dp, dsubcld, jt, mx, ideep, lengath, dt, pcols=16, out=None):
+        """winds: [2][ncol][pver] (u, v)."""
+        _, n, pver = winds.shape
+        if out is None:
+            out = {k: self.empty(2, n, pver) for k in abi.MOMTRAN_OUT_3D}
+            out["seten"] = self.empty(n, pver)
+        io = abi.MomtranIO()
+        for k, v in dict(winds=winds, mu=mu, md=md, du=du, eu=eu, ed=ed, dp=dp, dsubcld=dsubcld).items():
+            setattr(io, k, _p(self._f64(v)))
+        for k, v in dict(jt=jt, mx=mx, ideep=ideep, lengath=lengath).items():
+            assert v.dtype == self.torch.int32 and v.is_cuda
+            setattr(io, k, _p(v, abi.PI))
+        for k, v in out.items():
+            setattr(io, k, _p(self._f64(v)))
+        self._check(self.lib.colphys_momtran_dev(C.c_int(n), C.c_int(pver), C.c_int(pcols), C.c_double(dt), C.byref(io),
+                                                 self._stream()))
+        return out
+
+    # ---- modal aerosol optics (modal_aer_opt.F90:485,1216) ------------------------------------------
+    def aero_tables_set(self, props: dict, physconst: dict):
+        self._keep = []
+        self.tables = abi.build_aero_tables(props, physconst, self._keep)
+        self._check(self.lib.colphys_aero_tables_set(C.byref(self.tables)))
+
+    def _aero_io(self, pdeldry, specmmr, dgnumwet, qaerwat, pmid=None, t=None):
+        io = abi.ModalAeroIO()
+        io.pdeldry = _p(self._f64(pdeldry)); io.specmmr = _p(self._f64(specmmr))
+        io.dgnumwet = _p(self._f64(dgnumwet)); io.qaerwat = _p(self._f64(qaerwat))
+        io.pmid = _p(pmid) if pmid is not None else None
+        io.t = _p(t) if t is not None else None
+        return io
+
+    def modal_aero_sw(self, pdeldry, specmmr, dgnumwet, qaerwat, out=None):
+        n, pver = pdeldry.shape
+        nsw = self.tables.nswbands
+        if out is None:
+            out = {k: self.empty(n, nsw, pver + 1) for k in ("tauxar", "wa", "ga", "fa")}
+            out["status"] = self.empty(n, dtype=self.torch.int32)
+        io = self._aero_io(pdeldry, specmmr, dgnumwet, qaerwat)
+        for k in ("tauxar", "wa", "ga", "fa"):
+            setattr(io, k, _p(out[k]))
+        io.status = _p(out["status"], abi.PI)
+        self._check(self.lib.colphys_modal_aero_sw_dev(C.c_int(n), C.c_int(pver), C.byref(io), self._stream()))
+        return out
+
+    def modal_aero_lw(self, pdeldry, specmmr, dgnumwet, qaerwat, out=None):
+        n, pver = pdeldry.shape
+        nlw = self.tables.nlwbands
+        if out is None:
+            out = dict(tauxar=self.empty(n, nlw, pver), status=self.empty(n, dtype=self.torch.int32))
+        io = self._aero_io(pdeldry, specmmr, dgnumwet, qaerwat)
+        io.tauxar = _p(out["tauxar"]); io.status = _p(out["status"], abi.PI)
+        self._check(self.lib.colphys_modal_aero_lw_dev(C.c_int(n), C.c_int(pver), C.byref(io), self._stream()))
+        return out
+
+    # ---- measurement ---------------------------------------------------------------------------------
+    def profile_enable(self, on: bool):
+        self.lib.colphys_profile_enable(int(on))
+
+    def profile_reset(self):
+        self.lib.colphys_profile_reset()
+
+    def profile(self) -> dict:
+        res = {}
+        for i, name in enumerate(abi.KERNEL_NAMES):
+            ms, n = C.c_double(), C.c_int64()
+            self.lib.colphys_profile_get(i, C.byref(ms), C.byref(n))
+            res[name] = (ms.value, n.value)
+        return res

@@ -85,14 +85,15 @@ def geopotential_fv(state: dict) -> tuple[np.ndarray, np.ndarray]:
     return zi, zm
 
 
-def make_state(ncol: int, pver: int, seed: int = DEFAULT_SEED, *, moist_boost: float = 1.0) -> dict:
+def make_state(ncol: int, pver: int, seed: int = DEFAULT_SEED, *, moist_boost: float = 1.0,
+               ts_range=(275.0, 303.0), rh_range=(0.3, 0.95)) -> dict:
     """Tropical-ish soundings; 10-30 % of them trigger deep convection with ZM_NAMELIST."""
     c = PHYSCONST
     rng = np.random.Generator(np.random.PCG64(seed))
     ps = rng.uniform(95000.0, 103000.0, ncol)
-    ts = rng.uniform(275.0, 303.0, ncol)
+    ts = rng.uniform(ts_range[0], ts_range[1], ncol)
     gam = rng.uniform(5.5e-3, 7.0e-3, ncol)
-    rh = rng.uniform(0.3, 0.95, ncol)
+    rh = rng.uniform(rh_range[0], rh_range[1], ncol)
     sig = sigma_edges(pver)
     pint = PTOP + sig[None, :] * (ps[:, None] - PTOP)
     pmid = 0.5 * (pint[:, :-1] + pint[:, 1:])
@@ -191,7 +192,7 @@ def make_aero_state(ncol: int, pver: int, props: dict, seed: int = DEFAULT_SEED)
     aer["dgnumwet"][big] = rng.uniform(2.0e-5, 6.0e-5, big.sum())
     # a few slightly negative water contents exercise the watervol<0 reset (modal_aer_opt.F90:837-844)
     neg = rng.uniform(size=(nm, ncol, pver)) < 0.005
-    aer["qaerwat"][neg] *= -1.0e-3
+    aer["qaerwat"][neg] = -1.0e-16
     for m in range(nm):                       # unused species slots hold zeros
         aer["specmmr"][m, props["nspec"][m]:] = 0.0
     return aer

@@ -123,3 +123,36 @@ class RefOracle:
         self.lib.ref_momtran(C.c_int(n), _d(winds), *[_d(a) for a in ins], *[_i(a) for a in ints], C.c_double(dt),
                              *[_d(o[k]) for k in ("dqdt", "pguall", "pgdall", "icwu", "icwd", "seten")])
         return o
+
+    # -- modal aerosol optics ------------------------------------------------------------------------
+    def aero_tables_set(self, props, physconst):
+        """props as cam_nor_physics_amd.synth.make_aero_props(); same C layouts as colphys_aero_tables."""
+        from cam_nor_physics_amd import abi
+        self._aero_keep = []
+        tb = abi.build_aero_tables(props, physconst, self._aero_keep)
+        self.aero_dims = (tb.nmodes, tb.nspec_max, tb.nswbands, tb.nlwbands)
+        self.lib.ref_aero_set_tables(
+            C.c_int(tb.nmodes), C.c_int(tb.nspec_max), C.c_int(tb.top_lev), tb.nspec, tb.spectype, tb.sigmag, tb.specdens,
+            tb.hygro, tb.specrefindex_sw, tb.specrefindex_lw, tb.refrtabsw, tb.refitabsw, tb.refrtablw, tb.refitablw,
+            tb.extpsw, tb.abspsw, tb.asmpsw, tb.absplw, tb.crefwsw, tb.crefwlw)
+
+    def _aero_args(self, state, aer):
+        a = [_c(state[k]) for k in ("pdeldry", "pmid", "t")] + [_c(aer[k]) for k in ("specmmr", "dgnumwet", "qaerwat")]
+        tl = np.ascontiguousarray(aer["troplevchem"], dtype=np.int32)
+        return a, tl
+
+    def modal_aero_sw(self, state, aer):
+        n, pver = state["t"].shape
+        nsw = self.aero_dims[2]
+        a, tl = self._aero_args(state, aer)
+        o = {k: np.zeros((n, nsw, pver + 1)) for k in ("tauxar", "wa", "ga", "fa")}
+        self.lib.ref_modal_aero_sw(C.c_int(n), *[_d(x) for x in a], _i(tl), *[_d(o[k]) for k in ("tauxar", "wa", "ga", "fa")])
+        return o
+
+    def modal_aero_lw(self, state, aer):
+        n, pver = state["t"].shape
+        nlw = self.aero_dims[3]
+        a, tl = self._aero_args(state, aer)
+        o = dict(tauxar=np.zeros((n, nlw, pver)))
+        self.lib.ref_modal_aero_lw(C.c_int(n), *[_d(x) for x in a], _i(tl), _d(o["tauxar"]))
+        return o

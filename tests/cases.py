@@ -1,0 +1,62 @@
+"""Input builders shared by the parity tests (CPU oracle side and GPU side)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from cam_nor_physics_amd import abi, synth
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ZM_GOLDEN = ["zm_l32", "zm_l70", "zm_l32_cold", "zm_l32_pbl"]
+AERO_GOLDEN = ["aero_l32", "aero_l70"]
+PCOLS = 16
+
+
+def load_golden(name):
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    return {k: g[k] for k in g.files}
+
+
+def golden_namelist(g):
+    nl = {k: float(v) for k, v in zip(g["namelist_keys"], g["namelist_vals"])}
+    for k in ("num_cin", "org", "microp", "no_deep_pbl", "parcel_pbl"):
+        nl[k] = int(nl[k])
+    return nl
+
+
+def golden_params(g):
+    return abi.make_zm_params(synth.PHYSCONST, golden_namelist(g), int(g["limcnv"]))
+
+
+def default_params(pver):
+    return abi.make_zm_params(synth.PHYSCONST, synth.ZM_NAMELIST, synth.limcnv_from_pref(pver))
+
+
+def zm_args_from_golden(g):
+    """positional args of zm_convr(t, qh, pblh, zm, geos, zi, pap, paph, dpp, delt, tpert, landfrac)"""
+    return (g["in_t"], g["in_q"], g["in_pblh"], g["geo_fv_zm"], g["in_phis"], g["geo_fv_zi"], g["in_pmid"], g["in_pint"],
+            g["in_pdel"], 0.5 * synth.ZTODT, g["in_tpert"], g["in_landfrac"])
+
+
+def zm_args_from_state(st, zi, zm):
+    return (st["t"], st["q"], st["pblh"], zm, st["phis"], zi, st["pmid"], st["pint"], st["pdel"], 0.5 * synth.ZTODT,
+            st["tpert"], st["landfrac"])
+
+
+def geo_args(st_or_g, prefix=""):
+    s = st_or_g
+    k = (lambda n: s[prefix + n])
+    return (k("lnpint"), k("lnpmid"), k("pint"), k("pmid"), k("pdel"), k("rpdel"), k("t"))
+
+
+def evap_cold_case(ncol, pver, seed):
+    """zm_conv_evap inputs that exercise snow production, melting and surface snowfall: cold soundings
+    with a synthetic precipitation-production profile (negative in places, as downdraft evaporation gives)."""
+    st = synth.make_state(ncol, pver, seed, ts_range=(248.0, 284.0), rh_range=(0.4, 0.98))
+    rng = np.random.default_rng(seed + 3)
+    prd = rng.uniform(-2.0e-9, 4.0e-8, (ncol, pver))
+    prd[:, : pver // 4] = 0.0
+    prd[rng.uniform(size=ncol) < 0.2] = 0.0
+    prec = np.maximum((prd * st["pdel"]).sum(axis=1) / synth.PHYSCONST["gravit"] / 1000.0, 0.0)
+    return (st["t"], st["pmid"], st["pdel"], st["q"], st["landfrac"], prd, st["cld"], synth.ZTODT, prec)

@@ -1,0 +1,128 @@
+"""Generates the golden fixtures from the REFERENCE ITSELF: /root/reference/physics/{zm_conv,geopotential,
+modal_aer_opt}.F90 compiled unmodified by oracle/Makefile (liboracle_ref_p16_l<pver>.so).  Only runs where
+/root/reference exists; the .npz files it writes are committed, the reference source never is.
+
+    python tests/golden/make_golden.py
+
+Fixtures hold inputs AND reference outputs (fp64 / int32), a few dozen columns per configuration, chosen so
+that ~40 % of them trigger deep convection.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+
+from cam_nor_physics_amd import synth  # noqa: E402
+from ref_oracle import RefOracle  # noqa: E402
+
+PCOLS = 16
+
+
+def pick_columns(deep_mask, nwant, ndeep_want, seed):
+    rng = np.random.default_rng(seed)
+    deep = np.flatnonzero(deep_mask); shallow = np.flatnonzero(~deep_mask)
+    sel = np.concatenate([rng.choice(deep, min(ndeep_want, deep.size), replace=False),
+                          rng.choice(shallow, nwant - min(ndeep_want, deep.size), replace=False)])
+    rng.shuffle(sel)
+    return sel
+
+
+def subset(state, sel):
+    out = {}
+    for k, v in state.items():
+        out[k] = v[sel] if isinstance(v, np.ndarray) and v.shape[:1] == (state["ncol"],) else v
+    out["ncol"] = len(sel)
+    return out
+
+
+def zm_golden(pver, npool, nwant, ndeep, seed, variant):
+    ref = RefOracle(PCOLS, pver)
+    nl = dict(synth.ZM_NAMELIST)
+    nl.update(variant.get("namelist", {}))
+    limcnv = synth.limcnv_from_pref(pver)
+    ref.zm_convi(limcnv, nl)
+    c = synth.PHYSCONST
+    st = synth.make_state(npool, pver, seed, **variant.get("state", {}))
+    zi, zm = ref.geopotential_t(st["lnpint"], st["lnpmid"], st["pint"], st["pmid"], st["pdel"], st["rpdel"], st["t"],
+                                st["q"], st["rair"], c["gravit"], st["zvir"], dycore=1)
+    pre = ref.zm_convr(st["t"], st["q"], st["pblh"], zm, st["phis"], zi, st["pmid"], st["pint"], st["pdel"],
+                       0.5 * synth.ZTODT, st["tpert"], st["landfrac"])
+    deep_mask = pre["jctop"] < pver
+    sel = pick_columns(deep_mask, nwant, ndeep, seed + 1)
+    s = subset(st, sel)
+    g = {"in_" + k: s[k] for k in ("t", "q", "u", "v", "pint", "pmid", "pdel", "rpdel", "lnpint", "lnpmid", "phis", "pblh",
+                                    "tpert", "landfrac", "cld", "rair", "zvir")}
+    g["limcnv"] = np.int32(limcnv)
+    g["namelist_keys"] = np.array(sorted(nl)); g["namelist_vals"] = np.array([float(nl[k]) for k in sorted(nl)])
+    # geopotential_t, three dycore branches (SE with two thermodynamically active species)
+    q2 = np.stack([s["q"], 0.1 * s["q"]])
+    for dy, name in ((0, "eul"), (1, "fv"), (2, "se")):
+        zi_d, zm_d = ref.geopotential_t(s["lnpint"], s["lnpmid"], s["pint"], s["pmid"], s["pdel"], s["rpdel"], s["t"],
+                                        q2, s["rair"], c["gravit"], s["zvir"], dycore=dy, nspecies=2 if dy == 2 else 1)
+        g[f"geo_{name}_zi"] = zi_d; g[f"geo_{name}_zm"] = zm_d
+    zi, zm = g["geo_fv_zi"], g["geo_fv_zm"]
+    o = ref.zm_convr(s["t"], s["q"], s["pblh"], zm, s["phis"], zi, s["pmid"], s["pint"], s["pdel"], 0.5 * synth.ZTODT,
+                     s["tpert"], s["landfrac"])
+    for k, v in o.items():
+        g["zm_" + k] = v
+    dt = synth.ZTODT
+    t1 = s["t"] + o["heat"] / c["cpair"] * dt          # what physics_update hands zm_conv_evap (zm_conv_intr.F90:739)
+    q1 = s["q"] + o["qtnd"] * dt
+    g["in_evap_t"] = t1; g["in_evap_q"] = q1
+    e = ref.zm_conv_evap(t1, s["pmid"], s["pdel"], q1, s["landfrac"], o["rprd"], s["cld"], dt, o["prec"])
+    for k, v in e.items():
+        g["evap_" + k] = v
+    m = ref.momtran(s["u"], s["v"], o["mu"], o["md"], o["du"], o["eu"], o["ed"], o["dp"], o["dsubcld"], o["jt"], o["maxg"],
+                    o["ideep"], o["lengath"], dt)
+    for k, v in m.items():
+        g["mom_" + k] = v
+    return g
+
+
+CASES = {
+    # name: (pver, pool, columns, deep wanted, seed, variant)
+    "zm_l32": (32, 640, 64, 26, 20261004, {}),
+    "zm_l70": (70, 480, 32, 13, 20261005, {}),
+    # cold soundings: snow reaches the surface in zm_conv_evap, freezing branch of parcel_dilute
+    "zm_l32_cold": (32, 960, 32, 12, 20261006, {"state": {"ts_range": (262.0, 286.0), "rh_range": (0.6, 0.98)}}),
+    # PBL-mixed parcel, no convection inside the PBL, three CIN regions
+    "zm_l32_pbl": (32, 640, 32, 13, 20261007, {"namelist": {"parcel_pbl": 1, "no_deep_pbl": 1, "num_cin": 3}}),
+}
+
+def aero_golden(pver, ncol, seed):
+    ref = RefOracle(PCOLS, pver)
+    props = synth.make_aero_props(seed)
+    st = synth.make_state(ncol, pver, seed)
+    aer = synth.make_aero_state(ncol, pver, props, seed)
+    ref.aero_tables_set(props, synth.PHYSCONST)
+    sw = ref.modal_aero_sw(st, aer)
+    lw = ref.modal_aero_lw(st, aer)
+    g = {"seed": np.int64(seed), "in_pdeldry": st["pdeldry"], "in_pmid": st["pmid"], "in_t": st["t"]}
+    for k in ("specmmr", "dgnumwet", "qaerwat", "troplevchem"):
+        g["in_" + k] = aer[k]
+    for k, v in sw.items():
+        g["sw_" + k] = v
+    g["lw_tauxar"] = lw["tauxar"]
+    return g
+
+
+AERO_CASES = {"aero_l32": (32, 24, 20261004), "aero_l70": (70, 8, 20261005)}
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(CASES) + list(AERO_CASES)
+    for name in [w for w in which if w in AERO_CASES]:
+        g = aero_golden(*AERO_CASES[name])
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **g)
+        print(f"{name}: {g['in_t'].shape}, tau max {g['sw_tauxar'].max():.3e}, {os.path.getsize(path)/1e6:.2f} MB")
+    for name in [w for w in which if w in CASES]:
+        g = zm_golden(*CASES[name])
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **g)
+        nd = int(g["zm_lengath"].sum())
+        print(f"{name}: {g['in_t'].shape[0]} columns x L{g['in_t'].shape[1]}, {nd} deep, "
+              f"snow max {g['evap_snow'].max():.3e}, {os.path.getsize(path)/1e6:.2f} MB")

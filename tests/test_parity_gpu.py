@@ -1,0 +1,286 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libcolphys_hip.so), against
+  (a) the golden fixtures generated from the reference Fortran itself (tests/golden/make_golden.py),
+  (b) the C restatement (oracle/colphys_oracle.c) on fresh seeded inputs,
+  (c) size-independent properties at BASELINE.json's full size (48 602 columns): column independence,
+      chunk-width independence, gathered-layout consistency.
+Tolerance 1e-10 relative (tests/util.py); integer outputs identical.
+"""
+import numpy as np
+import pytest
+
+import cases
+from cam_nor_physics_amd import abi, synth
+from util import assert_close, gathered_mask
+
+pytestmark = pytest.mark.gpu
+
+_engines = {}
+
+
+def engine(params):
+    """one engine per process; colphys_init may be called again to change parameters"""
+    from cam_nor_physics_amd.engine import ColumnPhysics
+    eng = _engines.get("e")
+    if eng is None:
+        eng = ColumnPhysics(params, 0)
+        _engines["e"] = eng
+    else:
+        eng._check(eng.lib.colphys_init(0, params))
+        eng.params = params
+    return eng
+
+
+def to_np(o):
+    return {k: v.cpu().numpy() for k, v in o.items()}
+
+
+def run_zm(eng, args, pcols=cases.PCOLS):
+    t, qh, pblh, zm, geos, zi, pap, paph, dpp, delt, tpert, landfrac = args
+    d = eng.dev
+    o = eng.zm_convr(d(t), d(qh), d(pblh), d(zm), d(geos), d(zi), d(pap), d(paph), d(dpp), delt, d(tpert), d(landfrac), pcols=pcols)
+    eng.torch.cuda.synchronize()
+    return to_np(o)
+
+
+def check_zm(o, ref, ncol, pcols=cases.PCOLS):
+    assert np.array_equal(o["lengath"], ref["lengath"]), (o["lengath"], ref["lengath"])
+    m = gathered_mask(ref["lengath"], ncol, pcols)
+    worst = 0.0
+    for k in abi.ZM_CONVR_OUT_MID + abi.ZM_CONVR_OUT_INT + abi.ZM_CONVR_OUT_COL + ("jt", "maxg", "ideep"):
+        a, b = o[k], ref[k]
+        if k in abi.ZM_CONVR_GATHERED or k == "ideep":
+            assert not np.any(a[~m]), f"{k}: slots beyond lengath must be zero"
+            a, b = a[m], b[m]
+        worst = max(worst, assert_close("zm_convr." + k, a, b))
+    assert not o["status"].any()
+    return worst
+
+
+# ---------------------------------------------------------------------------------------------------
+# (a) golden fixtures = outputs of the reference Fortran
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", cases.ZM_GOLDEN)
+def test_zm_convr_vs_reference_golden(name):
+    g = cases.load_golden(name)
+    eng = engine(cases.golden_params(g))
+    o = run_zm(eng, cases.zm_args_from_golden(g))
+    ref = {k[3:]: v for k, v in g.items() if k.startswith("zm_")}
+    check_zm(o, ref, g["in_t"].shape[0])
+    assert ref["lengath"].sum() > 0
+
+
+@pytest.mark.parametrize("name", cases.ZM_GOLDEN)
+def test_geopotential_vs_reference_golden(name):
+    g = cases.load_golden(name)
+    eng = engine(cases.golden_params(g))
+    d = eng.dev
+    q2 = np.stack([g["in_q"], 0.1 * g["in_q"]])
+    for dy, tag in ((abi.DYCORE_EUL, "eul"), (abi.DYCORE_FV, "fv"), (abi.DYCORE_SE, "se")):
+        zi, zm = eng.geopotential_t(d(g["in_lnpint"]), d(g["in_lnpmid"]), d(g["in_pint"]), d(g["in_pmid"]), d(g["in_pdel"]),
+                                    d(g["in_rpdel"]), d(g["in_t"]), d(q2), d(g["in_rair"]), synth.PHYSCONST["gravit"],
+                                    d(g["in_zvir"]), dycore=dy, nspecies=2 if dy == abi.DYCORE_SE else 1)
+        assert_close(f"geopotential_t[{tag}].zi", zi.cpu().numpy(), g[f"geo_{tag}_zi"])
+        assert_close(f"geopotential_t[{tag}].zm", zm.cpu().numpy(), g[f"geo_{tag}_zm"])
+
+
+@pytest.mark.parametrize("name", cases.ZM_GOLDEN)
+def test_evap_and_momtran_vs_reference_golden(name):
+    g = cases.load_golden(name)
+    eng = engine(cases.golden_params(g))
+    d = eng.dev
+    prec = d(g["zm_prec"].copy())
+    e = to_np(eng.zm_conv_evap(d(g["in_evap_t"]), d(g["in_pmid"]), d(g["in_pdel"]), d(g["in_evap_q"]), d(g["in_landfrac"]),
+                               d(g["zm_rprd"]), d(g["in_cld"]), synth.ZTODT, prec))
+    for k, v in e.items():
+        assert_close("zm_conv_evap." + k, v, g["evap_" + k])
+    winds = d(np.stack([g["in_u"], g["in_v"]]))
+    m = to_np(eng.momtran(winds, d(g["zm_mu"]), d(g["zm_md"]), d(g["zm_du"]), d(g["zm_eu"]), d(g["zm_ed"]), d(g["zm_dp"]),
+                          d(g["zm_dsubcld"]), d(g["zm_jt"]), d(g["zm_maxg"]), d(g["zm_ideep"]), d(g["zm_lengath"]), synth.ZTODT))
+    for k, v in m.items():
+        assert_close("momtran." + k, v, g["mom_" + k])
+
+
+@pytest.mark.parametrize("name", cases.AERO_GOLDEN)
+def test_modal_aero_vs_reference_golden(name):
+    g = cases.load_golden(name)
+    pver = g["in_t"].shape[1]
+    eng = engine(cases.default_params(pver))
+    eng.aero_tables_set(synth.make_aero_props(int(g["seed"])), synth.PHYSCONST)
+    d = eng.dev
+    a = (d(g["in_pdeldry"]), d(g["in_specmmr"]), d(g["in_dgnumwet"]), d(g["in_qaerwat"]))
+    sw = to_np(eng.modal_aero_sw(*a))
+    for k in ("tauxar", "wa", "ga", "fa"):
+        assert_close("modal_aero_sw." + k, sw[k], g["sw_" + k])
+    lw = to_np(eng.modal_aero_lw(*a))
+    assert_close("modal_aero_lw.tauxar", lw["tauxar"], g["lw_tauxar"])
+    assert not sw["status"].any() and not lw["status"].any()
+    assert (sw["tauxar"] >= 0).all() and (lw["tauxar"] >= 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# (b) C restatement on fresh seeded inputs, sizes the oracle finishes in seconds
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pver,ncol,seed", [(32, 3001, 11), (70, 801, 12), (26, 333, 13)])
+def test_full_chain_vs_c_oracle(pver, ncol, seed):
+    from c_oracle import COracle
+    params = cases.default_params(pver)
+    eng = engine(params)
+    co = COracle(params)
+    st = synth.make_state(ncol, pver, seed)
+    c = synth.PHYSCONST
+    d = eng.dev
+    ga = cases.geo_args(st)
+    zi_r, zm_r = co.geopotential_t(*ga, st["q"], st["rair"], c["gravit"], st["zvir"], dycore=abi.DYCORE_FV)
+    zi, zm = eng.geopotential_t(*[d(x) for x in ga], d(st["q"]), d(st["rair"]), c["gravit"], d(st["zvir"]))
+    assert_close("geopotential_t.zi", zi.cpu().numpy(), zi_r)
+    assert_close("geopotential_t.zm", zm.cpu().numpy(), zm_r)
+    args = cases.zm_args_from_state(st, zi_r, zm_r)
+    ref = co.zm_convr(*args)
+    o = run_zm(eng, args)
+    check_zm(o, ref, ncol)
+    frac = ref["lengath"].sum() / ncol
+    assert 0.02 < frac < 0.6, frac
+    # evap on the updated state, then momtran on the gathered fluxes
+    dt = synth.ZTODT
+    t1 = st["t"] + ref["heat"] / c["cpair"] * dt
+    q1 = st["q"] + ref["qtnd"] * dt
+    ea = (t1, st["pmid"], st["pdel"], q1, st["landfrac"], ref["rprd"], st["cld"], dt, ref["prec"])
+    e_ref = co.zm_conv_evap(*ea)
+    e = to_np(eng.zm_conv_evap(*[d(x) for x in ea[:7]], dt, d(ref["prec"].copy())))
+    for k, v in e.items():
+        assert_close("zm_conv_evap." + k, v, e_ref[k])
+    m_ref = co.momtran(st["u"], st["v"], ref["mu"], ref["md"], ref["du"], ref["eu"], ref["ed"], ref["dp"], ref["dsubcld"],
+                       ref["jt"], ref["maxg"], ref["ideep"], ref["lengath"], dt)
+    m = to_np(eng.momtran(d(np.stack([st["u"], st["v"]])), *[d(ref[k]) for k in ("mu", "md", "du", "eu", "ed", "dp", "dsubcld")],
+                          *[d(ref[k]) for k in ("jt", "maxg", "ideep", "lengath")], dt))
+    for k, v in m.items():
+        assert_close("momtran." + k, v, m_ref[k])
+
+
+def test_evap_snow_paths_vs_c_oracle():
+    from c_oracle import COracle
+    params = cases.default_params(32)
+    eng = engine(params)
+    co = COracle(params)
+    ea = cases.evap_cold_case(1500, 32, 21)
+    e_ref = co.zm_conv_evap(*ea)
+    assert e_ref["snow"].max() > 0 and (e_ref["tend_s_snwevmlt"] != 0).any()
+    d = eng.dev
+    e = to_np(eng.zm_conv_evap(*[d(x) for x in ea[:7]], ea[7], d(ea[8].copy())))
+    for k, v in e.items():
+        assert_close("zm_conv_evap." + k, v, e_ref[k])
+
+
+def test_modal_aero_vs_c_oracle():
+    from c_oracle import COracle
+    pver, ncol = 32, 700
+    params = cases.default_params(pver)
+    eng = engine(params)
+    co = COracle(params)
+    props = synth.make_aero_props(5)
+    st = synth.make_state(ncol, pver, 5)
+    aer = synth.make_aero_state(ncol, pver, props, 5)
+    eng.aero_tables_set(props, synth.PHYSCONST)
+    co.aero_tables_set(props, synth.PHYSCONST)
+    d = eng.dev
+    a = (d(st["pdeldry"]), d(aer["specmmr"]), d(aer["dgnumwet"]), d(aer["qaerwat"]))
+    sw, sw_ref = to_np(eng.modal_aero_sw(*a)), co.modal_aero_sw(st, aer)
+    lw, lw_ref = to_np(eng.modal_aero_lw(*a)), co.modal_aero_lw(st, aer)
+    for k in ("tauxar", "wa", "ga", "fa"):
+        assert_close("modal_aero_sw." + k, sw[k], sw_ref[k])
+    assert_close("modal_aero_lw.tauxar", lw["tauxar"], lw_ref["tauxar"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# (c) properties at BASELINE.json's full size
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_column_independence_and_gather():
+    """48 602 columns x L32: permuting the columns permutes the per-column results bit for bit; changing the
+    chunk width changes only the gathered layout; the gathered layout is a faithful ascending compaction."""
+    ncol, pver = 48602, 32
+    eng = engine(cases.default_params(pver))
+    st = synth.make_state(ncol, pver, 77)
+    args = cases.zm_args_from_state(st, st["zi"], st["zm"])
+    o16 = run_zm(eng, args, pcols=16)
+    full = ("qtnd", "heat", "cme", "zdu", "rprd", "dlf", "ql", "eurt", "mcon", "pflx", "prec", "jctop", "jcbot", "cape", "rliq")
+    for k in full:
+        assert np.isfinite(o16[k]).all(), k
+    deep = o16["jctop"] < pver            # deep columns have a plume top above the lowest level
+    nd = int(o16["lengath"].sum())
+    assert 0.03 * ncol < nd < 0.5 * ncol
+    # permutation
+    perm = np.random.default_rng(3).permutation(ncol)
+    pargs = tuple(a[perm] if isinstance(a, np.ndarray) else a for a in args)
+    op = run_zm(eng, pargs, pcols=16)
+    for k in full:
+        assert np.array_equal(op[k], o16[k][perm]), f"{k} depends on column order"
+    # chunk width
+    o48 = run_zm(eng, args, pcols=48)
+    for k in full:
+        assert np.array_equal(o48[k], o16[k]), f"{k} depends on pcols"
+    # gathered layout: ideep ascending per chunk, rows equal the full-layout values they came from
+    for pcols, o in ((16, o16), (48, o48)):
+        m = gathered_mask(o["lengath"], ncol, pcols)
+        rows = np.flatnonzero(m)
+        src = (rows // pcols) * pcols + o["ideep"][rows] - 1
+        assert int(m.sum()) == nd
+        assert np.all(np.diff(src) > 0)
+        assert np.array_equal(o["jt"][rows], o["jctop"][src].astype(np.int32))
+        assert np.array_equal(o["maxg"][rows], o["jcbot"][src].astype(np.int32))
+        assert np.array_equal(o["du"][rows], o["zdu"][src])          # zdu is the scattered du (zm_conv.F90:1504)
+        np.testing.assert_allclose(o["mu"][rows] + o["md"][rows], o["mcon"][src][:, :pver], rtol=1e-12, atol=1e-18)  # mc = mu + md
+        assert np.all(o["mu"][rows] >= 0) and np.all(o["md"][rows] <= 0)
+        assert np.all((o["prec"] >= 0)) and np.all(o["prec"][~np.isin(np.arange(ncol), src)] == 0)
+
+
+def test_chunk_entry_points_match_device_entry_points():
+    """The Fortran-facing (pcols,pver,nchunks) host-layout calls give the same numbers as the device calls."""
+    import ctypes as C
+    pver, pcols = 32, 16
+    ncols = np.array([16, 16, 9, 16, 1], dtype=np.int32)       # ragged chunks, as ne30's last chunk
+    nch = len(ncols)
+    eng = engine(cases.default_params(pver))
+    st = synth.make_state(int(ncols.sum()), pver, 31)
+    args = cases.zm_args_from_state(st, st["zi"], st["zm"])
+    # flat reference run: every chunk padded to pcols by repeating its first column is NOT what the flat call
+    # does, so compare per chunk against a flat run of exactly that chunk's columns
+    offs = np.concatenate([[0], np.cumsum(ncols)])
+
+    def to_chunks(a, nlev):
+        out = np.full((nch, nlev, pcols), np.inf)      # Fortran (pcols, nlev, nchunks)
+        for c in range(nch):
+            blk = a[offs[c]:offs[c + 1]].reshape(ncols[c], nlev)
+            out[c, :, :ncols[c]] = blk.T
+        return np.ascontiguousarray(out)
+
+    names_mid = ("t", "qh", "pap", "dpp", "zm")
+    vals = dict(t=args[0], qh=args[1], pblh=args[2], zm=args[3], geos=args[4], zi=args[5], pap=args[6], paph=args[7],
+                dpp=args[8], tpert=args[10], landfrac=args[11])
+    hin = {k: to_chunks(vals[k], pver) for k in names_mid}
+    hin.update({k: to_chunks(vals[k], pver + 1) for k in ("paph", "zi")})
+    hin.update({k: to_chunks(vals[k], 1) for k in ("geos", "pblh", "tpert", "landfrac")})
+    hout = {k: np.zeros((nch, pver, pcols)) for k in abi.ZM_CONVR_OUT_MID}
+    hout.update({k: np.zeros((nch, pver + 1, pcols)) for k in abi.ZM_CONVR_OUT_INT})
+    hout.update({k: np.zeros((nch, 1, pcols)) for k in abi.ZM_CONVR_OUT_COL})
+    hout.update({k: np.zeros((nch, 1, pcols), dtype=np.int32) for k in abi.ZM_CONVR_OUT_ICOL})
+    hout["lengath"] = np.zeros(nch, dtype=np.int32)
+    io = abi.ZmConvrIO()
+    for k, v in {**hin, **hout}.items():
+        setattr(io, k, abi.iptr(v) if v.dtype == np.int32 else abi.dptr(v))
+    rc = eng.lib.colphys_zm_convr_chunks(C.c_int(nch), C.c_int(pcols), C.c_int(pver), abi.iptr(ncols), C.c_double(args[9]), C.byref(io))
+    assert rc == 0, eng.lib.colphys_last_error()
+    for c in range(nch):
+        sl = slice(offs[c], offs[c + 1])
+        cargs = tuple(a[sl] if isinstance(a, np.ndarray) else a for a in args)
+        o = run_zm(eng, cargs, pcols=pcols)
+        n = ncols[c]
+        assert hout["lengath"][c] == o["lengath"][0]
+        lg = int(o["lengath"][0])
+        for k in ("qtnd", "heat", "rprd", "mcon", "pflx", "dlf", "ql"):
+            assert np.array_equal(hout[k][c, :, :n].T, o[k]), k
+        for k in ("prec", "cape", "jctop", "rliq"):
+            assert np.array_equal(hout[k][c, 0, :n], o[k]), k
+        for k in ("mu", "md", "eu", "dp"):
+            assert np.array_equal(hout[k][c, :, :lg].T, o[k][:lg]), k
+        for k in ("jt", "maxg", "ideep"):
+            assert np.array_equal(hout[k][c, 0, :lg], o[k][:lg]), k
