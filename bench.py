@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: columns/sec for one "ZM + geopotential + aerosol-optics" physics substep on
+synthetic ne30 x L32-shaped input (BASELINE.json: 48 602 columns x 32 levels), fp64.
+
+One step = one pass of the substep over this rank's columns, inputs already resident in HBM:
+
+    zm_convr -> physics_update -> geopotential_t -> zm_conv_evap -> physics_update -> geopotential_t
+             -> momtran -> physics_update -> geopotential_t -> modal_aero_sw -> modal_aero_lw
+
+(the call order of zm_conv_tend, zm_conv_intr.F90:662-836, followed by the two optics calls radiation makes,
+modal_aer_opt.F90:485,1216).  Algorithmic bytes of the substep: 52 128 B/column at L32.
+
+    python bench.py [--gpus N --steps K --warmup W]                 # N = 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: one process per GPU, static column split, NO collective on the data path; the only
+communication is the barrier / max-reduce that brackets the timed region.  Default is weak scaling (every rank
+owns a full 48 602-column ne30 slab, value = all ranks' columns / time); --strong splits ONE 48 602-column slab
+across the ranks instead (the literal reading of BASELINE.json's metric).
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on its launch stream) and
+`cpu_baseline` (the reference Fortran, or the C restatement if oracle/_ref is absent, on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+# algorithmic bytes per column (fp64), SURVEY.md 8d, as functions of pver = L
+BYTES = {
+    "geopotential_t": lambda L: 4 * L * 8 + (2 * L + 1) * 8,
+    "zm_convr": lambda L: (5 * L + 2 * (L + 1) + 4) * 8 + (17 * L + 2 * (L + 1) + 7) * 8 + 12,
+    "zm_conv_evap": lambda L: (6 * L + 2) * 8 + (6 * L + 2 * (L + 1) + 2) * 8,
+    "momtran": lambda L: (8 * L + 1) * 8 + 12 + 11 * L * 8,
+    "modal_aero_sw": lambda L: 26 * L * 8 + 4 * (L + 1) * 14 * 8,
+    "modal_aero_lw": lambda L: 26 * L * 8 + 16 * L * 8,
+}
+
+
+def substep_bytes(L):
+    return (BYTES["zm_convr"](L) + BYTES["zm_conv_evap"](L) + BYTES["momtran"](L) + 3 * BYTES["geopotential_t"](L)
+            + BYTES["modal_aero_sw"](L) + BYTES["modal_aero_lw"](L))
+
+
+def baseline_metric():
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "columns/sec, ZM+aer-opt physics substep, 48602 cols x L32 at 1/2/4/8 MI355X"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ncol", type=int, default=48602)
+    ap.add_argument("--pver", type=int, default=32)
+    ap.add_argument("--strong", action="store_true", help="split ONE --ncol slab over the ranks")
+    ap.add_argument("--no-aero", action="store_true", help="configs[1]: ZM only (zm_convr + zm_conv_evap + momtran)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    from cam_nor_physics_amd import synth
+    from cam_nor_physics_amd.dist import shard_range
+
+    pver = args.pver
+    with_aero = not args.no_aero
+    if args.strong:
+        lo, hi = shard_range(args.ncol, world, rank)
+        st_all = synth.make_state(args.ncol, pver, synth.DEFAULT_SEED)
+        st = {k: (v[lo:hi] if hasattr(v, "shape") and v.shape[:1] == (args.ncol,) else v) for k, v in st_all.items()}
+        st["ncol"] = hi - lo
+    else:
+        st = synth.make_state(args.ncol, pver, synth.DEFAULT_SEED + rank)
+    ncol = st["ncol"]
+    props = synth.make_aero_props(synth.DEFAULT_SEED)
+    aer = synth.make_aero_state(ncol, pver, props, synth.DEFAULT_SEED + rank)
+
+    # ---- CPU baseline: rank 0 at N = 1 only, BEFORE this process touches the GPU (workers are forked) ----
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from cpu_substep import run_cpu_baseline
+        cpu = run_cpu_baseline(st, aer, props, pver, with_aero=with_aero)
+
+    import torch
+    import torch.distributed as dist
+    from cam_nor_physics_amd import abi
+    from cam_nor_physics_amd.engine import ColumnPhysics
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    params = abi.make_zm_params(synth.PHYSCONST, synth.ZM_NAMELIST, synth.limcnv_from_pref(pver))
+    eng = ColumnPhysics(params, local_rank)
+    c = synth.PHYSCONST
+    d = eng.dev
+    dt = synth.ZTODT
+    pcols = 16
+
+    # ---- resident inputs (physics_state of this rank's columns) and pre-allocated outputs -----------------
+    S = {k: d(st[k]) for k in ("t", "q", "u", "v", "pint", "pmid", "pdel", "rpdel", "lnpint", "lnpmid", "pdeldry", "phis",
+                               "pblh", "tpert", "landfrac", "cld", "rair", "zvir", "zi", "zm")}
+    winds0 = torch.stack([S["u"], S["v"]]).contiguous()
+    zm_out = eng.alloc_zm_convr_out(ncol, pver, pcols)
+    t1, q1 = eng.empty(ncol, pver), eng.empty(ncol, pver)
+    winds1 = eng.empty(2, ncol, pver)
+    zi1, zm1 = eng.empty(ncol, pver + 1), eng.empty(ncol, pver)
+    prec1 = eng.empty(ncol)
+    ev_out = {k: eng.empty(ncol, pver) for k in abi.EVAP_OUT_MID}
+    ev_out.update({k: eng.empty(ncol, pver + 1) for k in abi.EVAP_OUT_INT})
+    ev_out["snow"] = eng.empty(ncol)
+    mom_out = {k: eng.empty(2, ncol, pver) for k in abi.MOMTRAN_OUT_3D}
+    mom_out["seten"] = eng.empty(ncol, pver)
+    if with_aero:
+        eng.aero_tables_set(props, c)
+        A = {k: d(aer[k]) for k in ("specmmr", "dgnumwet", "qaerwat")}
+        sw_out = {k: eng.empty(ncol, synth.NSWBANDS, pver + 1) for k in ("tauxar", "wa", "ga", "fa")}
+        sw_out["status"] = eng.empty(ncol, dtype=torch.int32)
+        lw_out = dict(tauxar=eng.empty(ncol, synth.NLWBANDS, pver), status=eng.empty(ncol, dtype=torch.int32))
+
+    def geo(t, q):
+        eng.geopotential_t(S["lnpint"], S["lnpmid"], S["pint"], S["pmid"], S["pdel"], S["rpdel"], t, q, S["rair"],
+                           c["gravit"], S["zvir"], zi=zi1, zm=zm1)
+
+    def substep():
+        # zm_conv_tend, zm_conv_intr.F90:662-836
+        eng.zm_convr(S["t"], S["q"], S["pblh"], S["zm"], S["phis"], S["zi"], S["pmid"], S["pint"], S["pdel"], 0.5 * dt,
+                     S["tpert"], S["landfrac"], pcols=pcols, out=zm_out)
+        eng.physics_update(dt, c["cpair"], t=(S["t"], zm_out["heat"], t1), q=(S["q"], zm_out["qtnd"], q1))       # :739
+        geo(t1, q1)
+        prec1.copy_(zm_out["prec"])
+        eng.zm_conv_evap(t1, S["pmid"], S["pdel"], q1, S["landfrac"], zm_out["rprd"], S["cld"], dt, prec1, out=ev_out)
+        eng.physics_update(dt, c["cpair"], t=(t1, ev_out["tend_s"], t1), q=(q1, ev_out["tend_q"], q1))            # :806
+        geo(t1, q1)
+        eng.momtran(winds0, zm_out["mu"], zm_out["md"], zm_out["du"], zm_out["eu"], zm_out["ed"], zm_out["dp"],
+                    zm_out["dsubcld"], zm_out["jt"], zm_out["maxg"], zm_out["ideep"], zm_out["lengath"], dt, pcols=pcols,
+                    out=mom_out)
+        eng.physics_update(dt, c["cpair"], t=(t1, mom_out["seten"], t1), u=(winds0[0], mom_out["dqdt"][0], winds1[0]),
+                           v=(winds0[1], mom_out["dqdt"][1], winds1[1]))                                            # :836
+        geo(t1, q1)
+        if with_aero:
+            eng.modal_aero_sw(S["pdeldry"], A["specmmr"], A["dgnumwet"], A["qaerwat"], out=sw_out)
+            eng.modal_aero_lw(S["pdeldry"], A["specmmr"], A["dgnumwet"], A["qaerwat"], out=lw_out)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        substep()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        substep()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+    cols = torch.tensor([float(ncol)], dtype=torch.float64, device=eng.device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cols, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    total_cols = float(cols.item())
+
+    # ---- per-kernel durations: HIP events on the launch stream, in a separate short pass ------------------
+    eng.profile_enable(True)
+    eng.profile_reset()
+    for _ in range(max(3, min(args.steps, 10))):
+        substep()
+    torch.cuda.synchronize()
+    prof = eng.profile()
+    eng.profile_enable(False)
+    ndeep = int(zm_out["lengath"].sum().item())
+    status_bad = int((zm_out["status"] != 0).sum().item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_cols * args.steps / elapsed
+        kern_ms = {k: v[0] for k, v in prof.items() if v[1] > 0}
+        per_call = {"geopotential_t": BYTES["geopotential_t"](pver), "zm_trigger": BYTES["zm_convr"](pver),
+                    "zm_conv_evap": BYTES["zm_conv_evap"](pver), "momtran": BYTES["momtran"](pver),
+                    "modal_aero_sw": BYTES["modal_aero_sw"](pver), "modal_aero_lw": BYTES["modal_aero_lw"](pver)}
+        # share of one substep: geopotential_t and physics_update run three times
+        share = {k: v * (3 if k in ("geopotential_t", "physics_update") else 1) for k, v in kern_ms.items()}
+        dom = max((k for k in share if k in per_call), key=lambda k: share[k])
+        units = ndeep if dom == "momtran" else ncol
+        ach = per_call[dom] * units / (kern_ms[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                    "avg_launch_ms": round(kern_ms[dom], 4), "bytes_per_column": per_call[dom], "columns_per_launch": units,
+                    "kernel_ms": {k: round(v, 4) for k, v in kern_ms.items()},
+                    "substep_bytes_per_column": substep_bytes(pver),
+                    "substep_hbm_frac": round(substep_bytes(pver) * value / world / 1e9 / HBM_PEAK_GBS, 6),
+                    "note": "path is fp64-transcendental / latency bound, not HBM bound (SURVEY.md 0-4, 8d)"}
+        out = {
+            "metric": baseline_metric(),
+            "value": round(value, 1), "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("ZM (zm_convr + zm_conv_evap + momtran) + 3x geopotential_t"
+                                    + (" + modal_aero_sw + modal_aero_lw" if with_aero else "")
+                                    + f", {args.ncol} columns x L{pver} per " + ("node" if args.strong else "GPU")),
+                       "columns_per_rank": ncol, "pver": pver, "pcols": pcols, "deep_fraction": round(ndeep / ncol, 4),
+                       "parallelism": f"static column split x{world}, no collectives on the data path",
+                       "columns_with_nonzero_status": status_bad},
+            "roofline": roofline,
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = {"value": round(cpu["value"], 1), "unit": cpu["unit"], "cores": cpu["cores"],
+                                   "kind": cpu["kind"], "sample": cpu["sample"], "seconds": round(cpu["seconds"], 3)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,8 +14,9 @@ STATUS_BRENT_NOT_CONVERGED = 1
 STATUS_DOPAER_RANGE = 2
 NCOEF, PREFR, PREFI = 5, 7, 10
 
-K_GEOPOTENTIAL, K_ZM_TRIGGER, K_ZM_PLUME, K_ZM_EVAP, K_MOMTRAN, K_AERO_SW, K_AERO_LW = range(7)
-KERNEL_NAMES = ["geopotential_t", "zm_trigger", "zm_plume", "zm_conv_evap", "momtran", "modal_aero_sw", "modal_aero_lw"]
+K_GEOPOTENTIAL, K_ZM_TRIGGER, K_ZM_PLUME, K_ZM_EVAP, K_MOMTRAN, K_AERO_SW, K_AERO_LW, K_UPDATE = range(8)
+KERNEL_NAMES = ["geopotential_t", "zm_trigger", "zm_plume", "zm_conv_evap", "momtran", "modal_aero_sw", "modal_aero_lw",
+                "physics_update"]
 
 
 class ZmParams(C.Structure):

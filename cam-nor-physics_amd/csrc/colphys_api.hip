@@ -349,6 +349,24 @@ int colphys_momtran_dev(int ncol, int pver, int pcols, double dt, const colphys_
     return rc ? fail(rc, "momtran launch failed") : COLPHYS_OK;
 }
 
+int colphys_physics_update_dev(int ncol, int pver, double dt, double cpair, double qmin, const double *t_in,
+                               const double *s_tend, double *t_out, const double *q_in, const double *q_tend, double *q_out,
+                               const double *u_in, const double *u_tend, double *u_out, const double *v_in,
+                               const double *v_tend, double *v_out, void *stream)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    auto triple_ok = [](const void *a, const void *b, const void *c) { return (a && b && c) || (!a && !b && !c); };
+    if (!triple_ok(t_in, s_tend, t_out) || !triple_ok(q_in, q_tend, q_out) || !triple_ok(u_in, u_tend, u_out) ||
+        !triple_ok(v_in, v_tend, v_out))
+        return fail(COLPHYS_ERR_ARG, "each (in, tend, out) triple must be all set or all NULL");
+    if (t_out && !(cpair > 0.0)) return fail(COLPHYS_ERR_ARG, "cpair must be > 0");
+    ProfScope ps(COLPHYS_K_UPDATE, (hipStream_t)stream);
+    rc = launch_physics_update(ncol, pver, dt, cpair, qmin, t_in, s_tend, t_out, q_in, q_tend, q_out, u_in, u_tend, u_out,
+                               v_in, v_tend, v_out, (hipStream_t)stream);
+    return rc ? fail(rc, "physics_update launch failed") : COLPHYS_OK;
+}
+
 // ---- aerosol tables -------------------------------------------------------------------------------------
 int colphys_aero_tables_set(const colphys_aero_tables *tb)
 {

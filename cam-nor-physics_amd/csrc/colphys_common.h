@@ -71,3 +71,7 @@ int launch_zm_conv_evap(const ZmDev &P, const double *estbl_dev, int ncol, int p
 int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, const colphys_momtran_io &io, hipStream_t st);
 int launch_modal_aero_sw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);
 int launch_modal_aero_lw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);
+int launch_physics_update(int ncol, int pver, double dt, double cpair, double qmin, const double *t_in,
+                          const double *s_tend, double *t_out, const double *q_in, const double *q_tend, double *q_out,
+                          const double *u_in, const double *u_tend, double *u_out, const double *v_in,
+                          const double *v_tend, double *v_out, hipStream_t st);

@@ -360,6 +360,24 @@ __global__ __launch_bounds__(NT) void momtran_kernel(ZmDev P, int ncol, int pver
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// physics_update (tendency application part), element-wise, grid-stride
+// ------------------------------------------------------------------------------------------------------
+__global__ void physics_update_kernel(size_t n, double dt, double cpair, double qmin, const double *__restrict__ t_in,
+                                      const double *__restrict__ s_tend, double *t_out, const double *__restrict__ q_in,
+                                      const double *__restrict__ q_tend, double *q_out, const double *__restrict__ u_in,
+                                      const double *__restrict__ u_tend, double *u_out, const double *__restrict__ v_in,
+                                      const double *__restrict__ v_tend, double *v_out)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (t_out) t_out[i] = t_in[i] + s_tend[i] * dt / cpair;            // physics_types.F90:427
+        if (q_out) q_out[i] = fmax(q_in[i] + q_tend[i] * dt, qmin);       // :321, qneg3 :329
+        if (u_out) u_out[i] = u_in[i] + u_tend[i] * dt;                   // :295
+        if (v_out) v_out[i] = v_in[i] + v_tend[i] * dt;                   // :303
+    }
+}
+
 inline int set_lds(const void *fn, size_t bytes)
 {
     if (bytes > 64 * 1024)
@@ -409,5 +427,17 @@ int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, con
         hipLaunchKernelGGL(momtran_kernel<76>, dim3(nblk), dim3(NT), 0, st, P, ncol, pver, pcols, dt, io);
     else
         hipLaunchKernelGGL(momtran_kernel<COLPHYS_MAX_PVER + 4>, dim3(nblk), dim3(NT), 0, st, P, ncol, pver, pcols, dt, io);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}
+
+int launch_physics_update(int ncol, int pver, double dt, double cpair, double qmin, const double *t_in,
+                          const double *s_tend, double *t_out, const double *q_in, const double *q_tend, double *q_out,
+                          const double *u_in, const double *u_tend, double *u_out, const double *v_in,
+                          const double *v_tend, double *v_out, hipStream_t st)
+{
+    const size_t n = (size_t)ncol * pver;
+    const int nblk = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(physics_update_kernel, dim3(nblk), dim3(256), 0, st, n, dt, cpair, qmin, t_in, s_tend, t_out, q_in,
+                       q_tend, q_out, u_in, u_tend, u_out, v_in, v_tend, v_out);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }

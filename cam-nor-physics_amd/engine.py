@@ -56,7 +56,7 @@ EXPORTED_SYMBOLS = [
     "colphys_zm_convr_dev", "colphys_zm_convr_chunks",
     "colphys_zm_conv_evap_dev", "colphys_zm_conv_evap_chunks",
     "colphys_momtran_dev", "colphys_momtran_chunks",
-    "colphys_aero_tables_set",
+    "colphys_physics_update_dev", "colphys_aero_tables_set",
     "colphys_modal_aero_sw_dev", "colphys_modal_aero_lw_dev",
     "colphys_modal_aero_sw_chunks", "colphys_modal_aero_lw_chunks",
     "colphys_profile_enable", "colphys_profile_reset", "colphys_profile_get",
@@ -187,6 +187,17 @@ class ColumnPhysics:
         self._check(self.lib.colphys_momtran_dev(C.c_int(n), C.c_int(pver), C.c_int(pcols), C.c_double(dt), C.byref(io),
                                                  self._stream()))
         return out
+
+    # ---- physics_update, tendency application (physics_types.F90:292-340,425-432) ---------------------
+    def physics_update(self, dt, cpair, qmin=1.0e-12, t=None, q=None, u=None, v=None):
+        """each of t, q, u, v is None or a triple (in, tend, out) of [ncol][pver] tensors"""
+        first = next(x for x in (t, q, u, v) if x is not None)
+        n, pver = first[0].shape
+        ptrs = []
+        for tri in (t, q, u, v):
+            ptrs += [None, None, None] if tri is None else [_p(self._f64(x)) for x in tri]
+        self._check(self.lib.colphys_physics_update_dev(C.c_int(n), C.c_int(pver), C.c_double(dt), C.c_double(cpair),
+                                                        C.c_double(qmin), *ptrs, self._stream()))
 
     # ---- modal aerosol optics (modal_aer_opt.F90:485,1216) ------------------------------------------
     def aero_tables_set(self, props: dict, physconst: dict):

@@ -187,6 +187,22 @@ int colphys_momtran_chunks(int nchunks, int pcols, int pver, const int32_t *ncol
                            const colphys_momtran_io *io);
 
 /* ---------------------------------------------------------------------------------------------------
+ * physics_update, the part the path needs between its three kernels (physics_types.F90:292-340, 425-432;
+ * called at zm_conv_intr.F90:739,806,836): apply tendencies over dt, out of place (state -> state1 is
+ * physics_state_copy, zm_conv_intr.F90:579):
+ *     t_out = t_in + s_tend*dt/cpair            (:427)
+ *     q_out = max(q_in + q_tend*dt, qmin)       (:321 + qneg3 clip, :329; qneg3 itself is upstream code)
+ *     u_out = u_in + u_tend*dt, v likewise      (:295, :303)
+ * Any (in, tend, out) triple may be all-NULL to skip that field; in == out is allowed.
+ * The caller follows with colphys_geopotential_t_dev, as physics_update does (:435-441).
+ * ------------------------------------------------------------------------------------------------- */
+int colphys_physics_update_dev(int ncol, int pver, double dt, double cpair, double qmin,
+                               const double *t_in, const double *s_tend, double *t_out,
+                               const double *q_in, const double *q_tend, double *q_out,
+                               const double *u_in, const double *u_tend, double *u_out,
+                               const double *v_in, const double *v_tend, double *v_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * modal aerosol optics  (modal_aer_opt.F90)
  *   Tables (host pointers, copied to the device once):
  *     sigmag[nmodes]; nspec[nmodes]; specdens, hygro [nmodes][nspec_max]; spectype [nmodes][nspec_max]
@@ -243,6 +259,7 @@ int colphys_modal_aero_lw_chunks(int nchunks, int pcols, int pver, const int32_t
 #define COLPHYS_K_MOMTRAN      4
 #define COLPHYS_K_AERO_SW      5
 #define COLPHYS_K_AERO_LW      6
+#define COLPHYS_K_UPDATE       7
 #define COLPHYS_K_COUNT        8
 int colphys_profile_enable(int on);
 int colphys_profile_reset(void);
