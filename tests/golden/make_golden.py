@@ -25,10 +25,12 @@ PCOLS = 16
 def pick_columns(deep_mask, nwant, ndeep_want, seed):
     rng = np.random.default_rng(seed)
     deep = np.flatnonzero(deep_mask); shallow = np.flatnonzero(~deep_mask)
-    sel = np.concatenate([rng.choice(deep, min(ndeep_want, deep.size), replace=False),
-                          rng.choice(shallow, nwant - min(ndeep_want, deep.size), replace=False)])
-    rng.shuffle(sel)
-    return sel
+    nd = min(ndeep_want, deep.size)
+    sh = rng.choice(shallow, nwant - nd, replace=False)
+    rest = np.concatenate([rng.choice(deep, nd, replace=False), sh[PCOLS:]])
+    rng.shuffle(rest)
+    # the first chunk holds no deep column: zm_convr takes its early return there (zm_conv.F90:917)
+    return np.concatenate([sh[:PCOLS], rest])
 
 
 def subset(state, sel):
@@ -110,6 +112,21 @@ def aero_golden(pver, ncol, seed):
     return g
 
 
+def evap_cold_golden(ncol, pver, seed):
+    """zm_conv_evap alone on cold soundings with a synthetic precipitation-production profile: snow production,
+    melting, surface snowfall (none of which the warm deep-convection columns above reach)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    ref = RefOracle(PCOLS, pver)
+    ref.zm_convi(synth.limcnv_from_pref(pver), synth.ZM_NAMELIST)
+    ea = cases.evap_cold_case(ncol, pver, seed)
+    e = ref.zm_conv_evap(*ea)
+    g = {"seed": np.int64(seed), "ncol": np.int64(ncol), "pver": np.int64(pver)}
+    for k, v in e.items():
+        g["evap_" + k] = v
+    return g
+
+
 AERO_CASES = {"aero_l32": (32, 24, 20261004), "aero_l70": (70, 8, 20261005)}
 
 if __name__ == "__main__":
@@ -119,6 +136,10 @@ if __name__ == "__main__":
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **g)
         print(f"{name}: {g['in_t'].shape}, tau max {g['sw_tauxar'].max():.3e}, {os.path.getsize(path)/1e6:.2f} MB")
+    if not sys.argv[1:] or "evap_cold" in which:
+        g = evap_cold_golden(48, 32, 21)
+        np.savez_compressed(os.path.join(HERE, "evap_cold.npz"), **g)
+        print(f"evap_cold: snow max {g['evap_snow'].max():.3e}, melting levels {(g['evap_tend_s_snwevmlt'] != 0).sum()}")
     for name in [w for w in which if w in CASES]:
         g = zm_golden(*CASES[name])
         path = os.path.join(HERE, name + ".npz")

@@ -69,7 +69,7 @@ def test_golden_fixtures_cover_the_branches():
         g = cases.load_golden(name)
         n = g["in_t"].shape[0]
         assert 0.2 * n < g["zm_lengath"].sum() < 0.6 * n          # deep and non-deep columns both present
-        assert (g["zm_lengath"] == 0).any() or name != "zm_l32"     # at least one chunk takes the early return
+        assert g["zm_lengath"][0] == 0                             # first chunk takes the early return (:917)
 
 
 def test_column_independence_of_the_oracle():
@@ -97,3 +97,12 @@ def test_water_budget_of_zm_convr():
     deep = o["prec"] > 0
     assert deep.sum() > 20
     np.testing.assert_allclose(o["prec"][deep], col[deep], rtol=1e-9)
+
+
+def test_evap_snow_paths_vs_reference_golden():
+    g = cases.load_golden("evap_cold")
+    ea = cases.evap_cold_case(int(g["ncol"]), int(g["pver"]), int(g["seed"]))
+    e = COracle(cases.default_params(int(g["pver"]))).zm_conv_evap(*ea)
+    assert g["evap_snow"].max() > 0 and (g["evap_tend_s_snwevmlt"] != 0).any() and (g["evap_tend_s_snwprd"] != 0).any()
+    for k, v in e.items():
+        assert_close("zm_conv_evap." + k, v, g["evap_" + k])

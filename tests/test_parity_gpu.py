@@ -171,6 +171,16 @@ def test_evap_snow_paths_vs_c_oracle():
         assert_close("zm_conv_evap." + k, v, e_ref[k])
 
 
+def test_evap_snow_paths_vs_reference_golden():
+    g = cases.load_golden("evap_cold")
+    eng = engine(cases.default_params(int(g["pver"])))
+    ea = cases.evap_cold_case(int(g["ncol"]), int(g["pver"]), int(g["seed"]))
+    d = eng.dev
+    e = to_np(eng.zm_conv_evap(*[d(x) for x in ea[:7]], ea[7], d(ea[8].copy())))
+    for k, v in e.items():
+        assert_close("zm_conv_evap." + k, v, g["evap_" + k])
+
+
 def test_modal_aero_vs_c_oracle():
     from c_oracle import COracle
     pver, ncol = 32, 700
