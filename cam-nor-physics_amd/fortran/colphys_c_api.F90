@@ -1,0 +1,103 @@
+! colphys_c_api -- ISO_C_BINDING view of include/colphys.h (the C ABI of libcolphys_hip.so).
+! Field order of every bind(C) type must match the header.
+module colphys_c_api
+  use iso_c_binding
+  implicit none
+  public
+
+  integer(c_int), parameter :: COLPHYS_OK = 0
+  integer(c_int), parameter :: COLPHYS_DYCORE_EUL = 0, COLPHYS_DYCORE_FV = 1, COLPHYS_DYCORE_SE = 2
+  integer(c_int), parameter :: COLPHYS_STATUS_BRENT_NOT_CONVERGED = 1, COLPHYS_STATUS_DOPAER_RANGE = 2
+
+  type, bind(C) :: colphys_zm_params
+    real(c_double) :: cpair, epsilo, gravit, latice, latvap, tmelt, rair, cpwv, cpliq, rh2o, cpvir, zvir
+    real(c_double) :: c0_lnd, c0_ocn, ke, ke_lnd, momcu, momcd, tiedke_add, capelmt, dmpdz_param, tau
+    real(c_double) :: tiedke_lnd, entrmn, alfadet, tentrm, plclmin, cin_threshd, parcel_hscale
+    integer(c_int32_t) :: limcnv, num_cin, zm_org, zmconv_microp, no_deep_pbl, lparcel_pbl, cam3, reserved
+  end type colphys_zm_params
+
+  type, bind(C) :: colphys_zm_convr_io
+    type(c_ptr) :: t, qh, pap, dpp, zm, paph, zi, geos, pblh, tpert, landfrac
+    type(c_ptr) :: qtnd, heat, cme, zdu, rprd, dlf, ql, dif, dnlf, dnif, eurt, mcon, pflx
+    type(c_ptr) :: prec, jctop, jcbot, cape, rliq, rice
+    type(c_ptr) :: mu, md, du, eu, ed, dp, dsubcld
+    type(c_ptr) :: jt, maxg, ideep, lengath, status
+  end type colphys_zm_convr_io
+
+  type, bind(C) :: colphys_zm_conv_evap_io
+    type(c_ptr) :: t, pmid, pdel, q, prdprec, cldfrc, landfrac, prec
+    type(c_ptr) :: tend_s, tend_s_snwprd, tend_s_snwevmlt, tend_q, ntprprd, ntsnprd, flxprec, flxsnow, snow
+  end type colphys_zm_conv_evap_io
+
+  type, bind(C) :: colphys_momtran_io
+    type(c_ptr) :: winds, mu, md, du, eu, ed, dp, dsubcld
+    type(c_ptr) :: jt, mx, ideep, lengath
+    type(c_ptr) :: dqdt, pguall, pgdall, icwu, icwd, seten
+  end type colphys_momtran_io
+
+  interface
+    integer(c_int) function colphys_device_count() bind(C, name='colphys_device_count')
+      import
+    end function
+    integer(c_int) function colphys_init(device, p) bind(C, name='colphys_init')
+      import
+      integer(c_int), value :: device
+      type(colphys_zm_params), intent(in) :: p
+    end function
+    integer(c_int) function colphys_finalize() bind(C, name='colphys_finalize')
+      import
+    end function
+    type(c_ptr) function colphys_last_error() bind(C, name='colphys_last_error')
+      import
+    end function
+    integer(c_int) function colphys_geopotential_t_chunks(nchunks, pcols, pver, ncol, dycore_kind, nq, nspecies, &
+         piln, pmln, pint, pmid, pdel, rpdel, t, q, rair, gravit, zvir, zi, zm) bind(C, name='colphys_geopotential_t_chunks')
+      import
+      integer(c_int), value :: nchunks, pcols, pver, dycore_kind, nq, nspecies
+      integer(c_int32_t), intent(in) :: ncol(*)
+      type(c_ptr), value :: piln, pmln, pint, pmid, pdel, rpdel, t, q, rair, zvir, zi, zm
+      real(c_double), value :: gravit
+    end function
+    integer(c_int) function colphys_zm_convr_chunks(nchunks, pcols, pver, ncol, delt, io) bind(C, name='colphys_zm_convr_chunks')
+      import
+      integer(c_int), value :: nchunks, pcols, pver
+      integer(c_int32_t), intent(in) :: ncol(*)
+      real(c_double), value :: delt
+      type(colphys_zm_convr_io), intent(in) :: io
+    end function
+    integer(c_int) function colphys_zm_conv_evap_chunks(nchunks, pcols, pver, ncol, deltat, io) &
+         bind(C, name='colphys_zm_conv_evap_chunks')
+      import
+      integer(c_int), value :: nchunks, pcols, pver
+      integer(c_int32_t), intent(in) :: ncol(*)
+      real(c_double), value :: deltat
+      type(colphys_zm_conv_evap_io), intent(in) :: io
+    end function
+    integer(c_int) function colphys_momtran_chunks(nchunks, pcols, pver, ncol, dt, io) bind(C, name='colphys_momtran_chunks')
+      import
+      integer(c_int), value :: nchunks, pcols, pver
+      integer(c_int32_t), intent(in) :: ncol(*)
+      real(c_double), value :: dt
+      type(colphys_momtran_io), intent(in) :: io
+    end function
+  end interface
+
+contains
+
+  ! C string of colphys_last_error() as a Fortran string
+  function colphys_error_message() result(msg)
+    character(len=256) :: msg
+    type(c_ptr) :: p
+    character(kind=c_char), pointer :: s(:)
+    integer :: i
+    msg = ' '
+    p = colphys_last_error()
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, s, (/ 256 /))
+    do i = 1, 256
+      if (s(i) == c_null_char) exit
+      msg(i:i) = s(i)
+    end do
+  end function colphys_error_message
+
+end module colphys_c_api
