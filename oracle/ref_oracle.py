@@ -41,8 +41,11 @@ def _c(a):
 
 
 class RefOracle:
-    def __init__(self, pcols: int = 16, pver: int = 32):
-        self.lib = C.CDLL(ref_lib_path(pcols, pver))
+    def __init__(self, pcols: int = 16, pver: int = 32, lib_path: str | None = None):
+        """lib_path: any library exporting the ref_* entry points of oracle/ref_wrap_zm.F90 -- the reference
+        build (default) or the product's Fortran shim built behind the same wrapper
+        (cam-nor-physics_amd/_build/libcolphys_shim_p<pcols>_l<pver>.so)."""
+        self.lib = C.CDLL(lib_path or ref_lib_path(pcols, pver))
         pc, pv = C.c_int(), C.c_int()
         self.lib.ref_dims(C.byref(pc), C.byref(pv))
         assert (pc.value, pv.value) == (pcols, pver)
