@@ -23,23 +23,26 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+def build_hip(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
+    """extra_flags / out: experiment builds (A/B variants of a kernel) next to the shipped library"""
+    if out is None and not force and not _stale():
         return LIB
     os.makedirs(BUILD, exist_ok=True)
     objs = []
+    tag = "" if out is None else "." + os.path.basename(out).replace(".so", "")
     for src in SOURCES:
-        obj = os.path.join(BUILD, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(BUILD, src.replace(".hip", tag + ".o"))
+        cmd = [HIPCC, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    lib = out or LIB
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -36,12 +36,13 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB):
-        if build_if_missing:
+    path = os.environ.get("COLPHYS_LIB", LIB)          # COLPHYS_LIB: A/B experiment builds only
+    if not os.path.exists(path):
+        if build_if_missing and path == LIB:
             build_hip()
         else:
-            raise ColphysError(f"{LIB} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
-    lib = C.CDLL(LIB)
+            raise ColphysError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(path)
     lib.colphys_last_error.restype = C.c_char_p
     lib.colphys_init.argtypes = [C.c_int, C.POINTER(abi.ZmParams)]
     lib.colphys_profile_get.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
