@@ -43,7 +43,16 @@ __device__ __forceinline__ void tile_out(double *g, const double *s, int nc, int
 
 // ------------------------------------------------------------------------------------------------------
 // geopotential_t
+//   Phase 1 (element-wise, every lane, flat index over the block's [GT columns][pver] slab => every HBM
+//            access coalesced): the two per-level increments  dzi = rog*tv*hkl,  dzm = rog*tv*hkk
+//            (geopotential.F90:222-245 / :282-305) go to two LDS tiles.
+//   Phase 2 (one lane per column): the bottom-up sums zi(k) = zi(k+1) + dzi(k), zm(k) = zi(k+1) + dzm(k), in the
+//            reference's order, in place in LDS (odd row stride: conflict-free).
+//   Phase 3: coalesced store of the two tiles.
+//   LDS = 2 tiles: 34 KB for 64 columns x L32 => 4 blocks per CU; all 64 lanes scan.
 // ------------------------------------------------------------------------------------------------------
+constexpr int GT = 64;        // columns per block
+
 __global__ __launch_bounds__(NT) void geopotential_kernel(int ncol, int pver, int dycore_kind, int nspecies,
                                                          const double *__restrict__ piln, const double *__restrict__ pint,
                                                          const double *__restrict__ pmid, const double *__restrict__ pdel,
@@ -53,77 +62,64 @@ __global__ __launch_bounds__(NT) void geopotential_kernel(int ncol, int pver, in
                                                          double *__restrict__ zi, double *__restrict__ zm)
 {
     extern __shared__ double smem[];
-    const int col0 = blockIdx.x * TILE;
-    const int nc = min(TILE, ncol - col0);
+    const int col0 = blockIdx.x * GT;
+    const int nc = min(GT, ncol - col0);
     const int pverp = pver + 1;
-    const int ld = ldk_of(pver), ldp = ldk_of(pverp);
+    const int ldp = ldk_of(pverp);
     const size_t L = (size_t)pver, LP = (size_t)pverp, F = (size_t)ncol * L;
+    double *sZI = smem;                   // [GT][ldp]: dzi(k) at [k], then zi(k); zi(pver+1) = 0 at [pver]
+    double *sZM = smem + GT * ldp;        // [GT][ldp]: dzm(k), then zm(k)
 
-    // tiles: A = hkl source 1 (piln | pdel), B = hkl source 2 (pint | pmid), R = rpdel, T, Q(tvfac), RA, ZV, ZI
-    double *sA = smem;                    // [TILE][ldp]
-    double *sB = sA + TILE * ldp;         // [TILE][ldp]
-    double *sR = sB + TILE * ldp;         // [TILE][ld]
-    double *sT = sR + TILE * ld;
-    double *sQ = sT + TILE * ld;
-    double *sRA = sQ + TILE * ld;
-    double *sZV = sRA + TILE * ld;
-    double *sZI = sZV + TILE * ld;        // [TILE][ldp]   (zm reuses sT)
-
-    if (dycore_kind == COLPHYS_DYCORE_FV) {
-        tile_in(sA, piln + col0 * LP, nc, pverp, ldp);
-        tile_in(sB, pint + col0 * LP, nc, pverp, ldp);
-        tile_in(sR, rpdel + col0 * L, nc, pver, ld);
-    } else {
-        tile_in(sA, pdel + col0 * L, nc, pver, ldp);
-        tile_in(sB, pmid + col0 * L, nc, pver, ldp);
-    }
-    tile_in(sT, t + col0 * L, nc, pver, ld);
-    tile_in(sQ, q + col0 * L, nc, pver, ld);
-    tile_in(sRA, rair + col0 * L, nc, pver, ld);
-    tile_in(sZV, zvir + col0 * L, nc, pver, ld);
-    __syncthreads();
-
-    if (dycore_kind == COLPHYS_DYCORE_SE) {          // generalised virtual temperature :255-275, 301
-        // tvfac needs sums over the thermodynamically active species: accumulate them straight from HBM,
-        // element-wise (coalesced), before the scan; sQ ends up holding tvfac/.. inputs: q1, then tvfac
-        const int n = nc * pver;
-        for (int i = threadIdx.x; i < n; i += NT) {
-            const int c = i / pver, k = i - c * pver;
-            double qfac = 1.0, sum_dry = 1.0;
-            for (int idx = 0; idx < nspecies; ++idx) qfac = qfac - q[idx * F + col0 * L + i];
-            qfac = 1.0 / qfac;
-            for (int idx = 0; idx < nspecies; ++idx) sum_dry = sum_dry + q[idx * F + col0 * L + i] * qfac;
-            sum_dry = 1.0 / sum_dry;
-            sQ[c * ld + k] = (1.0 + (sZV[c * ld + k] + 1.0) * sQ[c * ld + k] * qfac) * sum_dry;
+    const int n = nc * pver;
+    for (int i = threadIdx.x; i < n; i += NT) {
+        const int c = i / pver, k = i - c * pver;              // 0-based level
+        const size_t g = col0 * L + i;                         // flat index, mid-level fields
+        const size_t gi = (size_t)(col0 + c) * LP + k;         // flat index, interface fields
+        double hkl, hkk, tvfac;
+        if (dycore_kind == COLPHYS_DYCORE_FV) {                // :222-226
+            hkl = piln[gi + 1] - piln[gi];
+            hkk = 1.0 - pint[gi] * hkl * rpdel[g];
+        } else {                                               // :232-235
+            hkl = pdel[g] / pmid[g];
+            hkk = 0.5 * hkl;
         }
-        __syncthreads();
+        const double q1 = q[g];
+        if (dycore_kind == COLPHYS_DYCORE_SE) {                // generalised virtual temperature :255-275, 301
+            double qfac = 1.0, sum_dry = 1.0;
+            for (int idx = 0; idx < nspecies; ++idx) qfac = qfac - q[idx * F + g];
+            qfac = 1.0 / qfac;
+            for (int idx = 0; idx < nspecies; ++idx) sum_dry = sum_dry + q[idx * F + g] * qfac;
+            sum_dry = 1.0 / sum_dry;
+            tvfac = (1.0 + (zvir[g] + 1.0) * q1 * qfac) * sum_dry;
+        } else {
+            tvfac = 1.0 + zvir[g] * q1;                        // :241
+        }
+        const double rog = rair[g] / gravit;                   // :203
+        const double tv = t[g] * tvfac;
+        sZM[c * ldp + k] = rog * tv * hkk;                     // :244
+        sZI[c * ldp + k] = rog * tv * hkl;                     // :245
     }
+    __syncthreads();
 
     const int c = threadIdx.x;
     if (c < nc) {
-        double zi_kp1 = 0.0;                         // :207-209
+        double zi_kp1 = 0.0;                                   // :207-209
         sZI[c * ldp + pver] = 0.0;
-        for (int k = pver - 1; k >= 0; --k) {        // 0-based level index here
-            double hkl, hkk, tvfac;
-            if (dycore_kind == COLPHYS_DYCORE_FV) {  // :222-226
-                hkl = sA[c * ldp + k + 1] - sA[c * ldp + k];
-                hkk = 1.0 - sB[c * ldp + k] * hkl * sR[c * ld + k];
-            } else {                                 // :232-235
-                hkl = sA[c * ldp + k] / sB[c * ldp + k];
-                hkk = 0.5 * hkl;
-            }
-            if (dycore_kind == COLPHYS_DYCORE_SE) tvfac = sQ[c * ld + k];
-            else tvfac = 1.0 + sZV[c * ld + k] * sQ[c * ld + k];     // :241
-            const double rog = sRA[c * ld + k] / gravit;             // :203
-            const double tv = sT[c * ld + k] * tvfac;
-            sT[c * ld + k] = zi_kp1 + rog * tv * hkk;                // zm :244
-            zi_kp1 = zi_kp1 + rog * tv * hkl;                        // zi :245
+        for (int k = pver - 1; k >= 0; --k) {
+            sZM[c * ldp + k] = zi_kp1 + sZM[c * ldp + k];
+            zi_kp1 = zi_kp1 + sZI[c * ldp + k];
             sZI[c * ldp + k] = zi_kp1;
         }
     }
     __syncthreads();
-    tile_out(zi + col0 * LP, sZI, nc, pverp, ldp);
-    tile_out(zm + col0 * L, sT, nc, pver, ld);
+    for (int i = threadIdx.x; i < nc * pverp; i += NT) {
+        const int cc = i / pverp, k = i - cc * pverp;
+        zi[col0 * LP + i] = sZI[cc * ldp + k];
+    }
+    for (int i = threadIdx.x; i < n; i += NT) {
+        const int cc = i / pver, k = i - cc * pver;
+        zm[col0 * L + i] = sZM[cc * ldp + k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -393,11 +389,10 @@ int launch_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspec
                           double *zi, double *zm, hipStream_t st)
 {
     (void)nq;
-    const int ld = (pver & 1) ? pver : pver + 1, ldp = ((pver + 1) & 1) ? pver + 1 : pver + 2;
-    const size_t lds = (size_t)TILE * (3 * ldp + 5 * ld) * sizeof(double);
-    if (lds > 160 * 1024) return COLPHYS_ERR_UNSUPPORTED;
+    const int ldp = ((pver + 1) & 1) ? pver + 1 : pver + 2;
+    const size_t lds = (size_t)GT * 2 * ldp * sizeof(double);
     if (set_lds((const void *)geopotential_kernel, lds)) return COLPHYS_ERR_HIP;
-    const int nblk = (ncol + TILE - 1) / TILE;
+    const int nblk = (ncol + GT - 1) / GT;
     hipLaunchKernelGGL(geopotential_kernel, dim3(nblk), dim3(NT), lds, st, ncol, pver, dycore_kind, nspecies, piln, pint,
                        pmid, pdel, rpdel, t, q, rair, gravit, zvir, zi, zm);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;

@@ -66,6 +66,13 @@ __device__ __forceinline__ double enthalpy_d(const ZmDev &P, double TK, double p
 }
 
 // ientropy :5304-5414 (KIND 0) / ienthalpy :5460-5570 (KIND 1): Brent's method, bracket Tfg +- 10 K.
+//
+// Same iteration, same arithmetic per evaluation as the reference; three EXACT savings (identical bits):
+//  (1) qst(T) is carried with every bracket point, so the reference's closing `qsat_hPa(T)` (:5399, :5555) --
+//      a re-evaluation at a temperature that was already evaluated -- is a register move;
+//  (2) entropy: while the parcel is unsaturated at the trial temperature (qv = qt) the term
+//      log((p - e)/pref) does not depend on T: it is computed once per inversion and reused;
+//  (3) entropy: when saturated, qv = qst and log(qv/qst) = log(1) = 0 exactly: the logarithm is skipped.
 template <int KIND>
 __device__ __noinline__ int invert_brent(const ZmDev &P, double s, double p, double z, double qt, double &T, double &qst,
                                          double Tfg)
@@ -73,27 +80,51 @@ __device__ __noinline__ int invert_brent(const ZmDev &P, double s, double p, dou
     const int LOOPMAX = 100;
     const double EPS = 3.e-8;
     double a, b, c, d = 0.0, ebr = 0.0, fa, fb, fc, pbr, qbr, rbr, sbr, tol1, xm;
+    double qa, qb, qc;                         // qst at a, b, c
     const double tol = 0.001;
     bool converged = false;
 
-    auto feval = [&](double x) -> double {
-        if (KIND == 1) return enthalpy_d(P, x, p, qt, z) - s;
-        return entropy_d(P, x, p, qt) - s;
+    // T-independent pieces of entropy(T, p, qt) for the unsaturated branch (:5295-5298)
+    double lg_unsat = 0.0;
+    if (KIND == 0) {
+        const double e_unsat = qt * p / (P.eps1 + qt);
+        lg_unsat = log((p - e_unsat) / 1000.0);
+    }
+
+    auto feval = [&](double TK, double &qs_out) -> double {
+        const double L = P.rl - (P.cpliq - P.cpwv) * (TK - P.tfreez);
+        double est, qs;
+        qsat_hPa(P, TK, p, est, qs);
+        qs_out = qs;
+        const double qv = fmin(qt, qs);
+        if (KIND == 1) return ((P.cpres + qt * P.cpliq) * TK + L * qv + (1.0 + qt) * P.grav * z) - s;       // :5454
+        double lgp, lgq;
+        if (qv == qt) {                        // unsaturated (or exactly saturated): e depends on qt only
+            lgp = lg_unsat;
+            lgq = log(qv / qs);
+        } else {                               // saturated: qv = qs
+            const double e = qv * p / (P.eps1 + qv);
+            lgp = log((p - e) / 1000.0);
+            lgq = 0.0;                         // log(qs/qs)
+        }
+        return ((P.cpres + qt * P.cpliq) * log(TK / P.tfreez) - P.rgas * lgp + L * qv / TK - qv * P.rh2o * lgq) - s;   // :5297
     };
 
     a = Tfg - 10;
     b = Tfg + 10;
-    fa = feval(a);
-    fb = feval(b);
+    fa = feval(a, qa);
+    fb = feval(b, qb);
     c = b;
     fc = fb;
+    qc = qb;
 
     for (int i = 0; i <= LOOPMAX; ++i) {
         if ((fb > 0.0 && fc > 0.0) || (fb < 0.0 && fc < 0.0)) {
-            c = a; fc = fa; d = b - a; ebr = d;
+            c = a; fc = fa; qc = qa; d = b - a; ebr = d;
         }
         if (fabs(fc) < fabs(fb)) {
             a = b; b = c; c = a; fa = fb; fb = fc; fc = fa;
+            const double qt_ = qb; qa = qb; qb = qc; qc = qt_;
         }
         tol1 = 2.0 * EPS * fabs(b) + 0.5 * tol;
         xm = 0.5 * (c - b);
@@ -123,12 +154,12 @@ __device__ __noinline__ int invert_brent(const ZmDev &P, double s, double p, dou
         }
         a = b;
         fa = fb;
+        qa = qb;
         b = b + ((fabs(d) > tol1) ? d : copysign(tol1, xm));
-        fb = feval(b);
+        fb = feval(b, qb);
     }
     T = b;
-    double est;
-    qsat_hPa(P, T, p, est, qst);
+    qst = qb;                                  // = qsat_hPa(T, p) of :5399 / :5555, already evaluated at b
     return converged ? 0 : COLPHYS_STATUS_BRENT_NOT_CONVERGED;
 }
 
