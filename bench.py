@@ -49,6 +49,27 @@ def substep_bytes(L):
             + BYTES["modal_aero_sw"](L) + BYTES["modal_aero_lw"](L))
 
 
+PMC_KERNEL = {"geopotential_t": "geopotential_kernel", "zm_trigger": "zm_trigger_kernel", "zm_plume": "zm_plume_kernel",
+              "zm_conv_evap": "zm_conv_evap_kernel", "momtran": "momtran_kernel", "modal_aero_sw": "modal_aero_kernel<true>",
+              "modal_aero_lw": "modal_aero_kernel<false>"}
+
+
+def pmc_traffic_gb(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command
+    (scripts/pmc_passes.sh -> profiles/*_pmc_summary.csv): (2*FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE reads
+    half the bytes of a coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM); calibrated here on
+    physics_update_kernel, whose byte count is known exactly.  None if no summary is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")))
+    if not files:
+        return None
+    for r in csv.DictReader(open(files[-1])):
+        if r["kernel"].startswith(PMC_KERNEL.get(kernel, "?")) and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
+            return round((2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024 / 1e9, 4), os.path.basename(files[-1])
+    return None
+
+
 def baseline_metric():
     try:
         with open(os.path.join(ROOT, "BASELINE.json")) as f:
@@ -259,12 +280,16 @@ def main():
         units = ndeep if dom == "momtran" else ncol
         ach = per_call[dom] * units / (kern_ms[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "traffic_unit": "GB per launch",
+                    "algorithmic_gb_per_launch": round(per_call[dom] * units / 1e9, 4),
                     "avg_launch_ms": round(kern_ms[dom], 4), "bytes_per_column": per_call[dom], "columns_per_launch": units,
                     "kernel_ms": {k: round(v, 4) for k, v in kern_ms.items()},
                     "substep_bytes_per_column": substep_bytes(pver),
                     "substep_hbm_frac": round(substep_bytes(pver) * value / world / 1e9 / HBM_PEAK_GBS, 6),
                     "note": "path is fp64-transcendental / latency bound, not HBM bound (SURVEY.md 0-4, 8d)"}
+        tr = pmc_traffic_gb(dom) if (args.ncol == 48602 and pver == 32) else None
+        if tr is not None:
+            roofline["traffic"], roofline["traffic_source"] = tr
         out = {
             "metric": baseline_metric(),
             "value": round(value, 1), "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

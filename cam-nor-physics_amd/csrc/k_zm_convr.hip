@@ -278,8 +278,13 @@ __device__ void buoyan_dilute_d(const ZmDev &P, const ColIn &c, double pblt, dou
         s_tpv[k * WAVE] = (tpk + c.tpert) * (1.0 + qstpk / P.eps1) / (1.0 + qstpk);   // :5194
         if (STORE_TP) { tp[k] = tpk; qstp[k] = qstpk; }
     }
+    // The level loop is ~14 k instructions per iteration, so the four input values of the NEXT level are
+    // requested one iteration ahead: their (strided, usually L2-missing) loads complete under the Brent solves.
+    double t_nx = 0.0, q_nx = 0.0, pap_nx = 0.0, zm_nx = 0.0;
+    if (klaunch - 1 >= msg + 1) { t_nx = c.t[klaunch - 1]; q_nx = c.q[klaunch - 1]; pap_nx = c.pap[klaunch - 1]; zm_nx = c.zm[klaunch - 1]; }
     for (int k = klaunch - 1; k >= msg + 1; --k) {
-        const double tk = c.T(k), qk = c.Q(k), pk = c.Pm(k), zk = c.Z(k);
+        const double tk = t_nx, qk = q_nx, pk = pap_nx * 0.01, zk = zm_nx + c.zs;
+        if (k - 1 >= msg + 1) { t_nx = c.t[k - 1]; q_nx = c.q[k - 1]; pap_nx = c.pap[k - 1]; zm_nx = c.zm[k - 1]; }
         // -- sweep 1: entrain, mix enthalpy, invert for T (:5042-5106)
         const double dp = (pk - p_kp1);
         const double qtenv = 0.5 * (qk + q_kp1);
