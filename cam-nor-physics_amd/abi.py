@@ -14,9 +14,9 @@ STATUS_BRENT_NOT_CONVERGED = 1
 STATUS_DOPAER_RANGE = 2
 NCOEF, PREFR, PREFI = 5, 7, 10
 
-K_GEOPOTENTIAL, K_ZM_TRIGGER, K_ZM_PLUME, K_ZM_EVAP, K_MOMTRAN, K_AERO_SW, K_AERO_LW, K_UPDATE = range(8)
+K_GEOPOTENTIAL, K_ZM_TRIGGER, K_ZM_PLUME, K_ZM_EVAP, K_MOMTRAN, K_AERO_SW, K_AERO_LW, K_UPDATE, K_CONVTRAN = range(9)
 KERNEL_NAMES = ["geopotential_t", "zm_trigger", "zm_plume", "zm_conv_evap", "momtran", "modal_aero_sw", "modal_aero_lw",
-                "physics_update"]
+                "physics_update", "convtran"]
 
 
 class ZmParams(C.Structure):
@@ -96,6 +96,14 @@ class MomtranIO(C.Structure):
 
 
 MOMTRAN_OUT_3D = ("dqdt", "pguall", "pgdall", "icwu", "icwd")
+
+
+class ConvtranIO(C.Structure):
+    _fields_ = (
+        [(n, PD) for n in ("q", "fracis", "mu", "md", "du", "eu", "ed", "dp", "dpdry")]
+        + [(n, PI) for n in ("jt", "mx", "ideep", "lengath", "doconvtran", "isdry")]
+        + [("dqdt", PD)]
+    )
 
 
 class AeroTables(C.Structure):

@@ -349,6 +349,22 @@ int colphys_momtran_dev(int ncol, int pver, int pcols, double dt, const colphys_
     return rc ? fail(rc, "momtran launch failed") : COLPHYS_OK;
 }
 
+int colphys_convtran_dev(int ncol, int pver, int pcols, int ncnst, double dt, const colphys_convtran_io *io, void *stream)
+{
+    (void)dt;
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    if (!io) return fail(COLPHYS_ERR_ARG, "null io");
+    if (pcols < 1 || pcols > 1024 || ncnst < 1) return fail(COLPHYS_ERR_ARG, "bad pcols / ncnst");
+    const void *ptrs[] = {io->q, io->fracis, io->mu, io->md, io->du, io->eu, io->ed, io->dp, io->dpdry, io->jt, io->mx, io->ideep,
+                          io->lengath, io->doconvtran, io->isdry, io->dqdt};
+    for (const void *p : ptrs)
+        if (!p) return fail(COLPHYS_ERR_ARG, "null pointer in colphys_convtran_io");
+    ProfScope ps(COLPHYS_K_CONVTRAN, (hipStream_t)stream);
+    rc = launch_convtran(ncol, pver, pcols, ncnst, *io, (hipStream_t)stream);
+    return rc ? fail(rc, "convtran launch failed") : COLPHYS_OK;
+}
+
 int colphys_physics_update_dev(int ncol, int pver, double dt, double cpair, double qmin, const double *t_in,
                                const double *s_tend, double *t_out, const double *q_in, const double *q_tend, double *q_out,
                                const double *u_in, const double *u_tend, double *u_out, const double *v_in,
@@ -673,6 +689,37 @@ int colphys_momtran_chunks(int nchunks, int pcols, int pver, const int32_t *ncol
     for (int f = 0; f < 5; ++f)
         for (int m = 0; m < 2; ++m) s.back(h3[f] + (size_t)m * ncd * pver, (const double *)(o3[f] + (size_t)m * ncd * pver), pver, false, nullptr);
     s.back(io->seten, (const double *)d.seten, pver, false, nullptr);
+    return COLPHYS_OK;
+}
+
+int colphys_convtran_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, int ncnst, double dt,
+                            const colphys_convtran_io *io)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
+    if (!io || ncnst < 1) return fail(COLPHYS_ERR_ARG, "null io / bad ncnst");
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t ncd = (size_t)nchunks * pcols;
+    const size_t bytes = 8 * ncd * ((3 * (size_t)ncnst + 8) * pver + 8) + 4 * ncd * 4 + 64 * 256;
+    if ((rc = stage_reserve(2 * bytes, bytes))) return rc;
+    Stager s(nchunks, pcols, ncol, g_pin_arena.p, g_dev_arena.p);
+    colphys_convtran_io d = *io;
+    // q / fracis / dqdt: CAM (pcols,pver,ncnst) per chunk; the shim passes tracer-major (pcols,pver,nchunks,ncnst)
+    d.q = s.in_multi(io->q, pver, ncnst);
+    d.fracis = s.in_multi(io->fracis, pver, ncnst);
+    d.mu = s.in(io->mu, pver); d.md = s.in(io->md, pver); d.du = s.in(io->du, pver); d.eu = s.in(io->eu, pver);
+    d.ed = s.in(io->ed, pver); d.dp = s.in(io->dp, pver); d.dpdry = s.in(io->dpdry, pver);
+    d.jt = s.in_i(io->jt, 1); d.mx = s.in_i(io->mx, 1); d.ideep = s.in_i(io->ideep, 1);
+    int32_t *dl = s.dc.take<int32_t>(nchunks);
+    HIPCHK(hipMemcpy(dl, io->lengath, 4 * (size_t)nchunks, hipMemcpyHostToDevice));
+    d.lengath = dl;
+    double *dq = s.dc.take<double>((size_t)ncnst * ncd * pver);
+    d.dqdt = dq;
+    rc = colphys_convtran_dev((int)ncd, pver, pcols, ncnst, dt, &d, nullptr);
+    if (rc) return rc;
+    for (int m = 1; m < ncnst; ++m)
+        if (io->doconvtran[m])
+            s.back(io->dqdt + (size_t)m * ncd * pver, (const double *)(dq + (size_t)m * ncd * pver), pver, false, nullptr);
     return COLPHYS_OK;
 }
 

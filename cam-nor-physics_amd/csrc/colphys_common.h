@@ -75,3 +75,4 @@ int launch_physics_update(int ncol, int pver, double dt, double cpair, double qm
                           const double *s_tend, double *t_out, const double *q_in, const double *q_tend, double *q_out,
                           const double *u_in, const double *u_tend, double *u_out, const double *v_in,
                           const double *v_tend, double *v_out, hipStream_t st);
+int launch_convtran(int ncol, int pver, int pcols, int ncnst, const colphys_convtran_io &io, hipStream_t st);

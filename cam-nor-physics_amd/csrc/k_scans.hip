@@ -374,6 +374,111 @@ __global__ void physics_update_kernel(size_t n, double dt, double cpair, double 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// convtran :1976-2311 (non-microphysics path): one lane per (gathered column, tracer)
+//   grid.y = tracer m (1-based m+1 = 2..ncnst in the reference); tracers with doconvtran = 0 are skipped on the host.
+// ------------------------------------------------------------------------------------------------------
+template <int ML>
+__global__ __launch_bounds__(NT) void convtran_kernel(int ncol, int pver, int pcols, int m, int isdry, colphys_convtran_io io)
+{
+    const int row = blockIdx.x * NT + threadIdx.x;
+    if (row >= ncol) return;
+    const int ic = row / pcols, c0 = ic * pcols, slot = row - c0;
+    const int il2g = io.lengath[ic];
+    if (slot >= il2g) return;
+    const size_t L = (size_t)pver, F = (size_t)ncol * L;
+    const double small = 1.e-36, mbsth = 1.e-15;
+
+    int ktm = pver, kbm = pver;                                                  // :2055-2060 (per chunk)
+    for (int i = 0; i < il2g; ++i) {
+        ktm = min(ktm, io.jt[c0 + i]);
+        kbm = min(kbm, io.mx[c0 + i]);
+    }
+    const size_t ii = (size_t)(c0 + io.ideep[row] - 1);
+    const double *mu = io.mu + row * L - 1, *md = io.md + row * L - 1, *du = io.du + row * L - 1,
+                 *eu = io.eu + row * L - 1, *ed = io.ed + row * L - 1, *dp = io.dp + row * L - 1,
+                 *dpdry = io.dpdry + row * L - 1;
+    const double *qm = io.q + m * F + ii * L - 1, *fr = io.fracis + m * F + ii * L - 1;
+    double *dq = io.dqdt + m * F + ii * L - 1;
+    const int mx = io.mx[row];
+
+    double cnst[ML], chat[ML], cond[ML], conu[ML], efd[ML], edd[ML], dptmp[ML];   // efd = eutmp*fisg*const*dptmp, edd likewise
+    for (int k = 1; k <= pver; ++k) {                                            // :2065-2094
+        double dutmp, eutmp, edtmp;
+        if (isdry) {
+            dptmp[k] = dpdry[k];
+            dutmp = du[k] * dp[k] / dpdry[k];
+            eutmp = eu[k] * dp[k] / dpdry[k];
+            edtmp = ed[k] * dp[k] / dpdry[k];
+        } else {
+            dptmp[k] = dp[k]; dutmp = du[k]; eutmp = eu[k]; edtmp = ed[k];
+        }
+        cnst[k] = qm[k];
+        const double fisg = fr[k];
+        efd[k] = eutmp * fisg * cnst[k] * dptmp[k];                              // as grouped at :2143, :2157
+        edd[k] = edtmp * fisg * cnst[k] * dptmp[k];                              // :2146, :2168
+        conu[k] = dutmp;                                                         // parked until the updraft sweep
+    }
+    for (int k = 1; k <= pver; ++k) {                                            // :2099-2130
+        const int km1 = max(1, k - 1);
+        const double minc = fmin(cnst[km1], cnst[k]), maxc = fmax(cnst[km1], cnst[k]);
+        double cdifr;
+        if (minc < 0) cdifr = 0.0;
+        else cdifr = fabs(cnst[k] - cnst[km1]) / fmax(maxc, small);
+        if (cdifr > 1.E-6) {
+            const double cabv = fmax(cnst[km1], maxc * 1.e-12), cbel = fmax(cnst[k], maxc * 1.e-12);
+            chat[k] = log(cabv / cbel) / (cabv - cbel) * cabv * cbel;
+        } else {
+            chat[k] = 0.5 * (cnst[k] + cnst[km1]);
+        }
+        cond[k] = chat[k];
+    }
+    {                                                                            // :2133-2161 updraft, bottom to top
+        double conu_kp1 = 0.0;
+        for (int kk = pver; kk >= 1; --kk) {
+            const double dutmp = conu[kk];
+            const double mupdudp = mu[kk] + dutmp * dptmp[kk];
+            double cu = chat[kk];
+            if (mupdudp > mbsth) {
+                if (kk == pver) cu = (+efd[kk]) / mupdudp;
+                else cu = (mu[kk + 1] * conu_kp1 + efd[kk]) / mupdudp;
+            }
+            conu[kk] = cu;
+            conu_kp1 = cu;
+        }
+    }
+    if (md[2] < -mbsth) cond[2] = (-edd[1]) / md[2];                             // :2145-2147
+    for (int k = 3; k <= pver; ++k)                                              // :2164-2172
+        if (md[k] < -mbsth) cond[k] = (md[k - 1] * cond[k - 1] - edd[k - 1]) / md[k];
+
+    for (int k = 1; k <= pver; ++k) {
+        double dcondt = 0.0;
+        if (k >= ktm) {                                                          // :2175-2205
+            const int km1 = max(1, k - 1), kp1 = min(pver, k + 1);
+            const double fluxin = mu[kp1] * conu[kp1] + mu[k] * fmin(chat[k], cnst[km1])
+                                  - (md[k] * cond[k] + md[kp1] * fmin(chat[kp1], cnst[kp1]));
+            const double fluxout = mu[k] * conu[k] + mu[kp1] * fmin(chat[kp1], cnst[k])
+                                   - (md[kp1] * cond[kp1] + md[k] * fmin(chat[k], cnst[k]));
+            double netflux = fluxin - fluxout;
+            if (fabs(netflux) < fmax(fluxin, fluxout) * 1.e-12) netflux = 0.0;
+            dcondt = netflux / dptmp[k];
+        }
+        if (k >= kbm) {                                                          // :2208-2232
+            const int km1 = max(1, k - 1);
+            if (k == mx) {
+                const double fluxin = mu[k] * fmin(chat[k], cnst[km1]) - md[k] * cond[k];
+                const double fluxout = mu[k] * conu[k] - md[k] * fmin(chat[k], cnst[k]);
+                double netflux = fluxin - fluxout;
+                if (fabs(netflux) < fmax(fluxin, fluxout) * 1.e-12) netflux = 0.0;
+                dcondt = netflux / dptmp[k];
+            } else if (k > mx) {
+                dcondt = 0.0;
+            }
+        }
+        dq[k] = dcondt;                                                          // :2301-2306
+    }
+}
+
 inline int set_lds(const void *fn, size_t bytes)
 {
     if (bytes > 64 * 1024)
@@ -434,5 +539,23 @@ int launch_physics_update(int ncol, int pver, double dt, double cpair, double qm
     const int nblk = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(physics_update_kernel, dim3(nblk), dim3(256), 0, st, n, dt, cpair, qmin, t_in, s_tend, t_out, q_in,
                        q_tend, q_out, u_in, u_tend, u_out, v_in, v_tend, v_out);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}
+
+int launch_convtran(int ncol, int pver, int pcols, int ncnst, const colphys_convtran_io &io, hipStream_t st)
+{
+    const size_t n1 = (size_t)ncol * pver;
+    const int nblk = (ncol + NT - 1) / NT;
+    for (int m = 1; m < ncnst; ++m) {                       // do m = 2, ncnst (:2062)
+        if (!io.doconvtran[m]) continue;
+        if (hipMemsetAsync(io.dqdt + (size_t)m * n1, 0, n1 * sizeof(double), st) != hipSuccess) return COLPHYS_ERR_HIP;   // :2299
+        const int dry = io.isdry[m] ? 1 : 0;
+        if (pver <= 32)
+            hipLaunchKernelGGL(convtran_kernel<36>, dim3(nblk), dim3(NT), 0, st, ncol, pver, pcols, m, dry, io);
+        else if (pver <= 72)
+            hipLaunchKernelGGL(convtran_kernel<76>, dim3(nblk), dim3(NT), 0, st, ncol, pver, pcols, m, dry, io);
+        else
+            hipLaunchKernelGGL(convtran_kernel<COLPHYS_MAX_PVER + 4>, dim3(nblk), dim3(NT), 0, st, ncol, pver, pcols, m, dry, io);
+    }
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }

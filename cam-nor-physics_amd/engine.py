@@ -57,7 +57,7 @@ EXPORTED_SYMBOLS = [
     "colphys_zm_convr_dev", "colphys_zm_convr_chunks",
     "colphys_zm_conv_evap_dev", "colphys_zm_conv_evap_chunks",
     "colphys_momtran_dev", "colphys_momtran_chunks",
-    "colphys_physics_update_dev", "colphys_aero_tables_set",
+    "colphys_convtran_dev", "colphys_convtran_chunks", "colphys_physics_update_dev", "colphys_aero_tables_set",
     "colphys_modal_aero_sw_dev", "colphys_modal_aero_lw_dev",
     "colphys_modal_aero_sw_chunks", "colphys_modal_aero_lw_chunks",
     "colphys_profile_enable", "colphys_profile_reset", "colphys_profile_get",
@@ -188,6 +188,25 @@ class ColumnPhysics:
         self._check(self.lib.colphys_momtran_dev(C.c_int(n), C.c_int(pver), C.c_int(pcols), C.c_double(dt), C.byref(io),
                                                  self._stream()))
         return out
+
+    # ---- convtran (zm_conv.F90:1976) ---------------------------------------------------------------
+    def convtran(self, q, fracis, mu, md, du, eu, ed, dp, dpdry, jt, mx, ideep, lengath, doconvtran, isdry, dt, pcols=16,
+                 dqdt=None):
+        """q, fracis, dqdt: [ncnst][ncol][pver]; doconvtran / isdry: host sequences of ncnst flags."""
+        ncnst, n, pver = q.shape
+        if dqdt is None:
+            dqdt = self.torch.zeros_like(q)
+        io = abi.ConvtranIO()
+        for k, v in dict(q=q, fracis=fracis, mu=mu, md=md, du=du, eu=eu, ed=ed, dp=dp, dpdry=dpdry, dqdt=dqdt).items():
+            setattr(io, k, _p(self._f64(v)))
+        for k, v in dict(jt=jt, mx=mx, ideep=ideep, lengath=lengath).items():
+            assert v.dtype == self.torch.int32 and v.is_cuda
+            setattr(io, k, _p(v, abi.PI))
+        do = np.ascontiguousarray(doconvtran, dtype=np.int32); dry = np.ascontiguousarray(isdry, dtype=np.int32)
+        io.doconvtran = abi.iptr(do); io.isdry = abi.iptr(dry)
+        self._check(self.lib.colphys_convtran_dev(C.c_int(n), C.c_int(pver), C.c_int(pcols), C.c_int(ncnst), C.c_double(dt),
+                                                  C.byref(io), self._stream()))
+        return dqdt
 
     # ---- physics_update, tendency application (physics_types.F90:292-340,425-432) ---------------------
     def physics_update(self, dt, cpair, qmin=1.0e-12, t=None, q=None, u=None, v=None):

@@ -35,6 +35,12 @@ module colphys_c_api
     type(c_ptr) :: dqdt, pguall, pgdall, icwu, icwd, seten
   end type colphys_momtran_io
 
+  type, bind(C) :: colphys_convtran_io
+    type(c_ptr) :: q, fracis, mu, md, du, eu, ed, dp, dpdry
+    type(c_ptr) :: jt, mx, ideep, lengath, doconvtran, isdry
+    type(c_ptr) :: dqdt
+  end type colphys_convtran_io
+
   interface
     integer(c_int) function colphys_device_count() bind(C, name='colphys_device_count')
       import
@@ -79,6 +85,14 @@ module colphys_c_api
       integer(c_int32_t), intent(in) :: ncol(*)
       real(c_double), value :: dt
       type(colphys_momtran_io), intent(in) :: io
+    end function
+    integer(c_int) function colphys_convtran_chunks(nchunks, pcols, pver, ncol, ncnst, dt, io) &
+         bind(C, name='colphys_convtran_chunks')
+      import
+      integer(c_int), value :: nchunks, pcols, pver, ncnst
+      integer(c_int32_t), intent(in) :: ncol(*)
+      real(c_double), value :: dt
+      type(colphys_convtran_io), intent(in) :: io
     end function
   end interface
 

@@ -3,7 +3,7 @@
 ! Public procedures have the SAME names, argument lists, kinds and intents as the reference module zm_conv
 ! (NorESMhub/CAM-Nor-physics physics/zm_conv.F90):
 !     zm_convi      :115-120      zm_convr   :231-244 (intents :362-423)
-!     zm_conv_evap  :1712-1717    momtran    :2315-2319
+!     zm_conv_evap  :1712-1717    momtran    :2315-2319      convtran   :1976-1981
 ! so zm_conv_intr.F90 (`use zm_conv, only: zm_conv_evap, zm_convr, convtran, momtran`, :13; calls at :376,
 ! :662, :764, :822) compiles against it unchanged.  Each body marshals the caller's (pcols,pver) arrays to
 ! the C ABI's host-layout entry points (include/colphys.h, *_chunks), which pack exactly `ncol` columns, run
@@ -13,8 +13,7 @@
 ! -DCOLPHYS_DROPIN_NAMES it is `zm_conv`, a whole-module replacement -- that is how tests/ builds it against
 ! the very wrapper source that drives the reference (oracle/ref_wrap_zm.F90).
 !
-! Not offloaded: convtran (zm_conv.F90:1976; not part of the hot path, SURVEY.md 8f-1).  The whole-module
-! build carries a convtran that aborts with a message; a production build keeps the reference's convtran.
+! convtran (zm_conv.F90:1976, SURVEY.md 8f-1) is offloaded too (non-microphysics path).
 #ifdef COLPHYS_DROPIN_NAMES
 #define ZM_MODULE zm_conv
 #else
@@ -305,31 +304,52 @@ subroutine convtran(lchnk   , &
                     du      ,eu      ,ed      ,dp      ,dsubcld , &
                     jt      ,mx      ,ideep   ,il1g    ,il2g    , &
                     nstep   ,fracis  ,dqdt    ,dpdry   ,dt)
-   ! Same interface as zm_conv.F90:1976-1981.  Tracer transport is not on the offloaded path
-   ! (SURVEY.md 8f-1): production builds keep the reference's convtran (INTEGRATION.md).
+   ! Same interface as zm_conv.F90:1976-1981 (SURVEY.md 8f-1, the first "next" row).
+   use constituents, only: cnst_get_type_byind
    integer, intent(in) :: lchnk
    integer, intent(in) :: ncnst
    logical, intent(in) :: doconvtran(ncnst)
-   real(r8), intent(in) :: q(pcols,pver,ncnst)
-   real(r8), intent(in) :: mu(pcols,pver)
-   real(r8), intent(in) :: md(pcols,pver)
-   real(r8), intent(in) :: du(pcols,pver)
-   real(r8), intent(in) :: eu(pcols,pver)
-   real(r8), intent(in) :: ed(pcols,pver)
-   real(r8), intent(in) :: dp(pcols,pver)
+   real(r8), intent(in), target :: q(pcols,pver,ncnst)
+   real(r8), intent(in), target :: mu(pcols,pver)
+   real(r8), intent(in), target :: md(pcols,pver)
+   real(r8), intent(in), target :: du(pcols,pver)
+   real(r8), intent(in), target :: eu(pcols,pver)
+   real(r8), intent(in), target :: ed(pcols,pver)
+   real(r8), intent(in), target :: dp(pcols,pver)
    real(r8), intent(in) :: dsubcld(pcols)
-   real(r8), intent(in) :: fracis(pcols,pver,ncnst)
-   integer, intent(in) :: jt(pcols)
-   integer, intent(in) :: mx(pcols)
-   integer, intent(in) :: ideep(pcols)
+   real(r8), intent(in), target :: fracis(pcols,pver,ncnst)
+   integer, intent(in), target :: jt(pcols)
+   integer, intent(in), target :: mx(pcols)
+   integer, intent(in), target :: ideep(pcols)
    integer, intent(in) :: il1g
    integer, intent(in) :: il2g
    integer, intent(in) :: nstep
-   real(r8), intent(in) :: dpdry(pcols,pver)
+   real(r8), intent(in), target :: dpdry(pcols,pver)
    real(r8), intent(in) :: dt
-   real(r8), intent(out) :: dqdt(pcols,pver,ncnst)
-   dqdt = 0._r8
-   call endrun('convtran: not offloaded; link the reference convtran (INTEGRATION.md)')
+   real(r8), intent(out), target :: dqdt(pcols,pver,ncnst)
+
+   type(colphys_convtran_io) :: io
+   integer(c_int32_t), target :: ncol_c(1), lengath_c(1), do_c(ncnst), dry_c(ncnst)
+   integer(c_int) :: rc
+   integer :: m
+
+   if (zmconv_microp) call endrun('convtran (colphys): convective microphysics is outside the offloaded path')
+   if (il1g /= 1) call endrun('convtran (colphys): expects il1g=1 (zm_conv_intr.F90:875-879, 1020-1024)')
+   do m = 1, ncnst
+      do_c(m)  = merge(1, 0, doconvtran(m) .and. m >= 2)                 ! do m = 2, ncnst  (zm_conv.F90:2062)
+      dry_c(m) = merge(1, 0, cnst_get_type_byind(m) .eq. 'dry')
+      if (do_c(m) /= 0) dqdt(:,:,m) = 0._r8                              ! zm_conv.F90:2299
+   end do
+   io%q = c_loc(q); io%fracis = c_loc(fracis); io%mu = c_loc(mu); io%md = c_loc(md); io%du = c_loc(du)
+   io%eu = c_loc(eu); io%ed = c_loc(ed); io%dp = c_loc(dp); io%dpdry = c_loc(dpdry)
+   io%jt = c_loc(jt); io%mx = c_loc(mx); io%ideep = c_loc(ideep); io%lengath = c_loc(lengath_c)
+   io%doconvtran = c_loc(do_c); io%isdry = c_loc(dry_c); io%dqdt = c_loc(dqdt)
+   ! the gathered arrays are defined for 1:il2g only; ncol is not an argument of convtran: every column the
+   ! gathered set points at lies within 1:pcols, so the chunk is handed over at full width
+   ncol_c(1) = pcols
+   lengath_c(1) = il2g
+   rc = colphys_convtran_chunks(1, pcols, pver, ncol_c, ncnst, dt, io)
+   if (rc /= COLPHYS_OK) call endrun('**** CONVTRAN (colphys): '//trim(colphys_error_message())//' ****')
 end subroutine convtran
 
 end module ZM_MODULE

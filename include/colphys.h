@@ -13,6 +13,7 @@
  *                                     closure :4028, q1q2_pjr :4262, entropy/enthalpy/Brent :5280-5570)
  *   colphys_zm_conv_evap*            zm_conv_evap             physics/zm_conv.F90:1712-1972
  *   colphys_momtran*                 momtran                  physics/zm_conv.F90:2315-2715
+ *   colphys_convtran*                convtran                 physics/zm_conv.F90:1976-2311
  *   colphys_aero_tables_set          rad_cnst_get_mode_props / rad_cnst_get_aer_props data consumed at
  *                                    physics/modal_aer_opt.F90:717-721,759-762,1334-1355 and the water
  *                                    refractive indices crefwsw/crefwlw :59-60,1525-1530
@@ -187,6 +188,27 @@ int colphys_momtran_chunks(int nchunks, int pcols, int pver, const int32_t *ncol
                            const colphys_momtran_io *io);
 
 /* ---------------------------------------------------------------------------------------------------
+ * convtran  (zm_conv.F90:1976-1981): convective transport of tracers m = 2..ncnst on the gathered columns.
+ *   q, fracis, dqdt are [ncnst][ncol][pver] (tracer 1 = water vapour is never transported, :2062);
+ *   doconvtran[m], isdry[m] (cnst_get_type_byind(m) == 'dry', :2065) are HOST arrays of ncnst flags;
+ *   mass fluxes etc. are the gathered outputs of zm_convr; dpdry is gathered too (zm_conv_intr.F90:1010-1017).
+ *   dqdt(:,:,m) is defined (zero outside the gathered columns) for every tracer with doconvtran[m] != 0 and
+ *   left untouched for the others, as in the reference (:2299).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct colphys_convtran_io {
+    const double *q, *fracis;                        /* [ncnst][ncol][pver] */
+    const double *mu, *md, *du, *eu, *ed, *dp, *dpdry; /* gathered [ncol][pver] */
+    const int32_t *jt, *mx, *ideep;                  /* gathered [ncol] */
+    const int32_t *lengath;                          /* [nchunks] */
+    const int32_t *doconvtran, *isdry;               /* HOST [ncnst] */
+    double *dqdt;                                    /* [ncnst][ncol][pver] */
+} colphys_convtran_io;
+
+int colphys_convtran_dev(int ncol, int pver, int pcols, int ncnst, double dt, const colphys_convtran_io *io, void *stream);
+int colphys_convtran_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, int ncnst, double dt,
+                            const colphys_convtran_io *io);
+
+/* ---------------------------------------------------------------------------------------------------
  * physics_update, the part the path needs between its three kernels (physics_types.F90:292-340, 425-432;
  * called at zm_conv_intr.F90:739,806,836): apply tendencies over dt, out of place (state -> state1 is
  * physics_state_copy, zm_conv_intr.F90:579):
@@ -260,7 +282,8 @@ int colphys_modal_aero_lw_chunks(int nchunks, int pcols, int pver, const int32_t
 #define COLPHYS_K_AERO_SW      5
 #define COLPHYS_K_AERO_LW      6
 #define COLPHYS_K_UPDATE       7
-#define COLPHYS_K_COUNT        8
+#define COLPHYS_K_CONVTRAN     8
+#define COLPHYS_K_COUNT        10
 int colphys_profile_enable(int on);
 int colphys_profile_reset(void);
 int colphys_profile_get(int kernel, double *avg_ms, int64_t *launches);

@@ -108,6 +108,23 @@ class COracle:
         return o
 
     # --------------------------------------------------------------------------------------------
+    def convtran(self, q, fracis, mu, md, du, eu, ed, dp, dpdry, jt, mx, ideep, lengath, doconvtran, isdry, dt, pcols=16):
+        ncnst, n, pver = q.shape
+        f = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in dict(q=q, fracis=fracis, mu=mu, md=md, du=du, eu=eu, ed=ed,
+                                                                              dp=dp, dpdry=dpdry).items()}
+        i = {k: np.ascontiguousarray(v, dtype=np.int32) for k, v in dict(jt=jt, mx=mx, ideep=ideep, lengath=lengath,
+                                                                           doconvtran=doconvtran, isdry=isdry).items()}
+        dqdt = np.zeros((ncnst, n, pver))
+        io = abi.ConvtranIO()
+        for k, v in f.items():
+            setattr(io, k, abi.dptr(v))
+        for k, v in i.items():
+            setattr(io, k, abi.iptr(v))
+        io.dqdt = abi.dptr(dqdt)
+        self.lib.oracle_convtran(C.c_int(n), C.c_int(pver), C.c_int(pcols), C.c_int(ncnst), C.c_double(dt), C.byref(io))
+        return dqdt
+
+    # --------------------------------------------------------------------------------------------
     def aero_tables_set(self, props, physconst):
         self._keep = []
         self.tables = abi.build_aero_tables(props, physconst, self._keep)

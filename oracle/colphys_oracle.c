@@ -1291,6 +1291,112 @@ void oracle_momtran(int ncol, int pver, int pcols, double dt, const colphys_momt
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * convtran :1976-2311 (non-microphysics path), tracers 2..ncnst on the gathered columns
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_convtran(int ncol, int pver, int pcols, int ncnst, double dt, const colphys_convtran_io *io)
+{
+    const int nchunks = (ncol + pcols - 1) / pcols;
+    const size_t L = (size_t)pver, F = (size_t)ncol * L;
+    const double small = 1.e-36, mbsth = 1.e-15;
+    (void)dt;
+    for (int m = 1; m < ncnst; ++m)                                              /* dqdt(:,:,m) = 0 :2299 */
+        if (io->doconvtran[m])
+            for (size_t i = 0; i < F; ++i) io->dqdt[m * F + i] = 0.0;
+
+    for (int ic = 0; ic < nchunks; ++ic) {
+        const int c0 = ic * pcols;
+        const int il2g = io->lengath[ic];
+        int ktm = pver, kbm = pver;                                              /* :2055-2060 */
+        for (int i = 0; i < il2g; ++i) {
+            if (io->jt[c0 + i] < ktm) ktm = io->jt[c0 + i];
+            if (io->mx[c0 + i] < kbm) kbm = io->mx[c0 + i];
+        }
+        for (int m = 1; m < ncnst; ++m) {                                        /* do m = 2, ncnst */
+            if (!io->doconvtran[m]) continue;
+            for (int i = 0; i < il2g; ++i) {
+                const size_t row = (size_t)(c0 + i);
+                const size_t ii = (size_t)(c0 + io->ideep[row] - 1);
+                const double *mu = io->mu + row * L - 1, *md = io->md + row * L - 1, *du = io->du + row * L - 1,
+                             *eu = io->eu + row * L - 1, *ed = io->ed + row * L - 1, *dp = io->dp + row * L - 1,
+                             *dpdry = io->dpdry + row * L - 1;
+                const double *qm = io->q + m * F + ii * L - 1, *fr = io->fracis + m * F + ii * L - 1;
+                double *dq = io->dqdt + m * F + ii * L - 1;
+                const int mx = io->mx[row];
+                double cnst[NL], fisg[NL], chat[NL], cond[NL], conu[NL], dcondt[NL], dutmp[NL], eutmp[NL], edtmp[NL], dptmp[NL];
+
+                for (int k = 1; k <= pver; ++k) {                                /* :2065-2094 */
+                    if (io->isdry[m]) {
+                        dptmp[k] = dpdry[k];
+                        dutmp[k] = du[k] * dp[k] / dpdry[k];
+                        eutmp[k] = eu[k] * dp[k] / dpdry[k];
+                        edtmp[k] = ed[k] * dp[k] / dpdry[k];
+                    } else {
+                        dptmp[k] = dp[k]; dutmp[k] = du[k]; eutmp[k] = eu[k]; edtmp[k] = ed[k];
+                    }
+                    cnst[k] = qm[k];
+                    fisg[k] = fr[k];
+                }
+                for (int k = 1; k <= pver; ++k) {                                /* :2099-2130 */
+                    const int km1 = (k - 1 > 1) ? k - 1 : 1;
+                    double minc = fmin(cnst[km1], cnst[k]), maxc = fmax(cnst[km1], cnst[k]), cdifr;
+                    if (minc < 0) cdifr = 0.0;
+                    else cdifr = fabs(cnst[k] - cnst[km1]) / fmax(maxc, small);
+                    if (cdifr > 1.E-6) {
+                        double cabv = fmax(cnst[km1], maxc * 1.e-12), cbel = fmax(cnst[k], maxc * 1.e-12);
+                        chat[k] = log(cabv / cbel) / (cabv - cbel) * cabv * cbel;
+                    } else {
+                        chat[k] = 0.5 * (cnst[k] + cnst[km1]);
+                    }
+                    conu[k] = chat[k];
+                    cond[k] = chat[k];
+                    dcondt[k] = 0.0;
+                }
+                {                                                                /* :2133-2148 */
+                    const int k = 2, km1 = 1, kk = pver;
+                    double mupdudp = mu[kk] + dutmp[kk] * dptmp[kk];
+                    if (mupdudp > mbsth) conu[kk] = (+eutmp[kk] * fisg[kk] * cnst[kk] * dptmp[kk]) / mupdudp;
+                    if (md[k] < -mbsth) cond[k] = (-edtmp[km1] * fisg[km1] * cnst[km1] * dptmp[km1]) / md[k];
+                }
+                for (int kk = pver - 1; kk >= 1; --kk) {                         /* :2151-2161 */
+                    const int kkp1 = kk + 1;
+                    double mupdudp = mu[kk] + dutmp[kk] * dptmp[kk];
+                    if (mupdudp > mbsth)
+                        conu[kk] = (mu[kkp1] * conu[kkp1] + eutmp[kk] * fisg[kk] * cnst[kk] * dptmp[kk]) / mupdudp;
+                }
+                for (int k = 3; k <= pver; ++k) {                                /* :2164-2172 */
+                    const int km1 = k - 1;
+                    if (md[k] < -mbsth)
+                        cond[k] = (md[km1] * cond[km1] - edtmp[km1] * fisg[km1] * cnst[km1] * dptmp[km1]) / md[k];
+                }
+                for (int k = ktm; k <= pver; ++k) {                              /* :2175-2205 */
+                    const int km1 = (k - 1 > 1) ? k - 1 : 1, kp1 = (k + 1 < pver) ? k + 1 : pver;
+                    double fluxin = mu[kp1] * conu[kp1] + mu[k] * fmin(chat[k], cnst[km1])
+                                    - (md[k] * cond[k] + md[kp1] * fmin(chat[kp1], cnst[kp1]));
+                    double fluxout = mu[k] * conu[k] + mu[kp1] * fmin(chat[kp1], cnst[k])
+                                     - (md[kp1] * cond[kp1] + md[k] * fmin(chat[k], cnst[k]));
+                    double netflux = fluxin - fluxout;
+                    if (fabs(netflux) < fmax(fluxin, fluxout) * 1.e-12) netflux = 0.0;
+                    dcondt[k] = netflux / dptmp[k];
+                }
+                for (int k = kbm; k <= pver; ++k) {                              /* :2208-2232 */
+                    const int km1 = (k - 1 > 1) ? k - 1 : 1;
+                    if (k == mx) {
+                        double fluxin = mu[k] * fmin(chat[k], cnst[km1]) - md[k] * cond[k];
+                        double fluxout = mu[k] * conu[k] - md[k] * fmin(chat[k], cnst[k]);
+                        double netflux = fluxin - fluxout;
+                        if (fabs(netflux) < fmax(fluxin, fluxout) * 1.e-12) netflux = 0.0;
+                        dcondt[k] = netflux / dptmp[k];
+                    } else if (k > mx) {
+                        dcondt[k] = 0.0;
+                    }
+                }
+                for (int k = 1; k <= pver; ++k) dq[k] = dcondt[k];               /* :2301-2306 */
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * geopotential_t  /root/reference/physics/geopotential.F90:153-310
  * ---------------------------------------------------------------------------------------------- */
 void oracle_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspecies, const double *piln,

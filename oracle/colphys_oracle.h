@@ -27,6 +27,7 @@ void oracle_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspe
 void oracle_zm_convr(int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io *io);
 void oracle_zm_conv_evap(int ncol, int pver, double deltat, const colphys_zm_conv_evap_io *io);
 void oracle_momtran(int ncol, int pver, int pcols, double dt, const colphys_momtran_io *io);
+void oracle_convtran(int ncol, int pver, int pcols, int ncnst, double dt, const colphys_convtran_io *io);
 
 void oracle_aero_tables_set(const colphys_aero_tables *tb);
 void oracle_modal_aero_sw(int ncol, int pver, const colphys_modal_aero_io *io);

@@ -127,6 +127,18 @@ class RefOracle:
                              *[_d(o[k]) for k in ("dqdt", "pguall", "pgdall", "icwu", "icwd", "seten")])
         return o
 
+    # -- convtran ----------------------------------------------------------------------------------
+    def convtran(self, q, fracis, mu, md, du, eu, ed, dp, dpdry, jt, mx, ideep, lengath, doconvtran, isdry, dt):
+        ncnst, n, pver = q.shape
+        dqdt = np.zeros((ncnst, n, pver))
+        do = np.ascontiguousarray(doconvtran, dtype=np.int32); dry = np.ascontiguousarray(isdry, dtype=np.int32)
+        f = [_c(a) for a in (mu, md, du, eu, ed, dp)]
+        ints = [np.ascontiguousarray(a, dtype=np.int32) for a in (jt, mx, ideep, lengath)]
+        dsub = np.zeros(n)
+        self.lib.ref_convtran(C.c_int(n), C.c_int(ncnst), _i(do), _i(dry), _d(_c(q)), *[_d(a) for a in f], _d(dsub),
+                              *[_i(a) for a in ints], _d(_c(fracis)), _d(_c(dpdry)), C.c_double(dt), _d(dqdt))
+        return dqdt
+
     # -- modal aerosol optics ------------------------------------------------------------------------
     def aero_tables_set(self, props, physconst):
         """props as cam_nor_physics_amd.synth.make_aero_props(); same C layouts as colphys_aero_tables."""

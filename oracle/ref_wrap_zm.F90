@@ -16,7 +16,7 @@ module ref_wrap_zm
   use iso_c_binding
   use shr_kind_mod,    only: r8 => shr_kind_r8
   use ppgrid,          only: pcols, pver, pverp
-  use zm_conv,         only: zm_convi, zm_convr, zm_conv_evap, momtran
+  use zm_conv,         only: zm_convi, zm_convr, zm_conv_evap, momtran, convtran
   use geopotential,    only: geopotential_t
   use zm_microphysics, only: zm_conv_t, zm_aero_t
   implicit none
@@ -257,6 +257,48 @@ contains
       c0 = c0 + nc
     end do
   end subroutine ref_momtran
+
+  ! ---- convtran (zm_conv.F90:1976) ---------------------------------------------------------------
+  subroutine ref_convtran(n, ncnst, doconvtran, isdry, q, mu, md, du, eu, ed, dp, dsubcld, jt, mx, ideep, lengath, &
+       fracis, dpdry, dt, dqdt) bind(C, name='ref_convtran')
+    use constituents, only: cnst_is_dry
+    integer(c_int), value :: n, ncnst
+    integer(c_int), intent(in)  :: doconvtran(ncnst), isdry(ncnst)
+    real(c_double), intent(in)  :: q(pver,n,ncnst), fracis(pver,n,ncnst)
+    real(c_double), intent(in)  :: mu(pver,n), md(pver,n), du(pver,n), eu(pver,n), ed(pver,n), dp(pver,n), dpdry(pver,n)
+    real(c_double), intent(in)  :: dsubcld(n)
+    integer(c_int), intent(in)  :: jt(n), mx(n), ideep(n), lengath(*)
+    real(c_double), value       :: dt
+    real(c_double), intent(out) :: dqdt(pver,n,ncnst)
+    real(r8) :: q_c(pcols,pver,ncnst), f_c(pcols,pver,ncnst), dq_c(pcols,pver,ncnst)
+    real(r8) :: mu_c(pcols,pver), md_c(pcols,pver), du_c(pcols,pver), eu_c(pcols,pver), ed_c(pcols,pver), dp_c(pcols,pver), &
+                dpd_c(pcols,pver), ds_c(pcols)
+    integer  :: jt_c(pcols), mx_c(pcols), id_cc(pcols)
+    logical  :: doit(ncnst)
+    integer :: c0, nc, ic, m
+    doit = doconvtran /= 0
+    cnst_is_dry = .false.
+    cnst_is_dry(1:ncnst) = isdry /= 0
+    c0 = 0; ic = 0
+    do while (c0 < n)
+      nc = min(pcols, n - c0); ic = ic + 1
+      do m = 1, ncnst
+        call pack2(q(:,:,m), c0, nc, pver, q_c(:,:,m)); call pack2(fracis(:,:,m), c0, nc, pver, f_c(:,:,m))
+      end do
+      call pack2(mu, c0, nc, pver, mu_c); call pack2(md, c0, nc, pver, md_c); call pack2(du, c0, nc, pver, du_c)
+      call pack2(eu, c0, nc, pver, eu_c); call pack2(ed, c0, nc, pver, ed_c); call pack2(dp, c0, nc, pver, dp_c)
+      call pack2(dpdry, c0, nc, pver, dpd_c); call pack1(dsubcld, c0, nc, ds_c)
+      jt_c = 0; mx_c = 0; id_cc = 0
+      jt_c(1:nc) = jt(c0+1:c0+nc); mx_c(1:nc) = mx(c0+1:c0+nc); id_cc(1:nc) = ideep(c0+1:c0+nc)
+      dq_c = 0._r8
+      call convtran(ic, doit, q_c, ncnst, mu_c, md_c, du_c, eu_c, ed_c, dp_c, ds_c, jt_c, mx_c, id_cc, 1, lengath(ic), &
+                    0, f_c, dq_c, dpd_c, dt)
+      do m = 1, ncnst
+        call unpack2(dq_c(:,:,m), c0, nc, pver, dqdt(:,:,m))
+      end do
+      c0 = c0 + nc
+    end do
+  end subroutine ref_convtran
 
   ! ---- L0 seams (oracle/stubs/l0_arithmetic.F90), exported so the C restatement can be pinned to them ----
   subroutine ref_qsat_water(n, t, p, es, qs) bind(C, name='ref_qsat_water')

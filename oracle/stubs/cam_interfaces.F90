@@ -101,11 +101,13 @@ end module cam_history
 
 module constituents
   integer, parameter :: pcnst = 40
+  logical :: cnst_is_dry(pcnst) = .false.      ! set by the test driver (oracle/ref_wrap_zm.F90)
 contains
   function cnst_get_type_byind(m) result(t)
     integer, intent(in) :: m
     character(len=3) :: t
     t = 'wet'
+    if (cnst_is_dry(m)) t = 'dry'
   end function cnst_get_type_byind
 end module constituents
 

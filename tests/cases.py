@@ -60,3 +60,29 @@ def evap_cold_case(ncol, pver, seed):
     prd[rng.uniform(size=ncol) < 0.2] = 0.0
     prec = np.maximum((prd * st["pdel"]).sum(axis=1) / synth.PHYSCONST["gravit"] / 1000.0, 0.0)
     return (st["t"], st["pmid"], st["pdel"], st["q"], st["landfrac"], prd, st["cld"], synth.ZTODT, prec)
+
+
+NCNST = 6
+DOCONVTRAN = np.array([0, 1, 1, 0, 1, 1], dtype=np.int32)     # tracer 1 (water vapour) is never transported
+ISDRY = np.array([0, 0, 1, 0, 1, 0], dtype=np.int32)
+
+
+def convtran_inputs(pdel, qv, ideep, lengath, seed, pcols=PCOLS):
+    """tracer fields [NCNST][ncol][pver], insoluble fractions, and the gathered dry pressure thickness in mb
+    (zm_conv_intr.F90:1010-1017: dpdry(i,:) = state%pdeldry(ideep(i),:)/100)."""
+    ncol, pver = pdel.shape
+    rng = np.random.default_rng(seed)
+    lev = np.linspace(0.0, 1.0, pver)[None, None, :]
+    q = rng.uniform(0.2, 1.0, (NCNST, ncol, 1)) * 1.0e-6 * (0.05 + lev ** rng.uniform(0.5, 3.0, (NCNST, ncol, 1)))
+    q *= 1.0 + 0.2 * rng.standard_normal((NCNST, ncol, pver))
+    q[2, :, : pver // 3] = 0.0                                  # exact zeros: the small-difference branch
+    q[4, ::7, pver // 2] *= -1.0                                # a few negative values: minc < 0 branch
+    fracis = rng.uniform(0.0, 1.0, (NCNST, ncol, pver))
+    pdeldry = pdel * (1.0 - qv)
+    dpdry = np.zeros((ncol, pver))
+    for c in range(len(lengath)):
+        for j in range(int(lengath[c])):
+            row = c * pcols + j
+            dpdry[row] = pdeldry[c * pcols + int(ideep[row]) - 1] / 100.0
+    dpdry[dpdry == 0.0] = 1.0                                   # slots beyond lengath are never read; keep them finite
+    return np.ascontiguousarray(q), np.ascontiguousarray(fracis), dpdry

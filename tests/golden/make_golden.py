@@ -82,6 +82,12 @@ def zm_golden(pver, npool, nwant, ndeep, seed, variant):
                     o["ideep"], o["lengath"], dt)
     for k, v in m.items():
         g["mom_" + k] = v
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    cq, cf, cdp = cases.convtran_inputs(s["pdel"], s["q"], o["ideep"], o["lengath"], seed + 5)
+    g["ct_dqdt"] = ref.convtran(cq, cf, o["mu"], o["md"], o["du"], o["eu"], o["ed"], o["dp"], cdp, o["jt"], o["maxg"], o["ideep"],
+                                o["lengath"], cases.DOCONVTRAN, cases.ISDRY, dt)
+    g["ct_seed"] = np.int64(seed + 5)
     return g
 
 

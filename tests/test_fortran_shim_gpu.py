@@ -54,3 +54,7 @@ def test_fortran_caller_on_hip_engine_matches_reference_golden(name):
                    g["zm_jt"], g["zm_maxg"], g["zm_ideep"], g["zm_lengath"], synth.ZTODT)
     for k, v in mo.items():
         assert_close("momtran." + k, v, g["mom_" + k])
+    cq, cf, cdp = cases.convtran_inputs(g["in_pdel"], g["in_q"], g["zm_ideep"], g["zm_lengath"], int(g["ct_seed"]))
+    ct = f.convtran(cq, cf, g["zm_mu"], g["zm_md"], g["zm_du"], g["zm_eu"], g["zm_ed"], g["zm_dp"], cdp, g["zm_jt"], g["zm_maxg"],
+                    g["zm_ideep"], g["zm_lengath"], cases.DOCONVTRAN, cases.ISDRY, synth.ZTODT)
+    assert_close("convtran.dqdt", ct, g["ct_dqdt"])

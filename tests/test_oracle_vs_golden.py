@@ -31,6 +31,11 @@ def test_zm_chain_vs_reference_golden(name):
                     g["zm_dsubcld"], g["zm_jt"], g["zm_maxg"], g["zm_ideep"], g["zm_lengath"], synth.ZTODT)
     for k, v in mo.items():
         assert_close("momtran." + k, v, g["mom_" + k])
+    cq, cf, cdp = cases.convtran_inputs(g["in_pdel"], g["in_q"], g["zm_ideep"], g["zm_lengath"], int(g["ct_seed"]))
+    ct = co.convtran(cq, cf, g["zm_mu"], g["zm_md"], g["zm_du"], g["zm_eu"], g["zm_ed"], g["zm_dp"], cdp, g["zm_jt"], g["zm_maxg"],
+                     g["zm_ideep"], g["zm_lengath"], cases.DOCONVTRAN, cases.ISDRY, synth.ZTODT)
+    assert np.abs(g["ct_dqdt"]).max() > 0 and not g["ct_dqdt"][0].any() and not g["ct_dqdt"][3].any()
+    assert_close("convtran.dqdt", ct, g["ct_dqdt"])
 
 
 @pytest.mark.parametrize("name", cases.ZM_GOLDEN)

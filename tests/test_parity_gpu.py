@@ -98,6 +98,10 @@ def test_evap_and_momtran_vs_reference_golden(name):
                           d(g["zm_dsubcld"]), d(g["zm_jt"]), d(g["zm_maxg"]), d(g["zm_ideep"]), d(g["zm_lengath"]), synth.ZTODT))
     for k, v in m.items():
         assert_close("momtran." + k, v, g["mom_" + k])
+    cq, cf, cdp = cases.convtran_inputs(g["in_pdel"], g["in_q"], g["zm_ideep"], g["zm_lengath"], int(g["ct_seed"]))
+    ct = eng.convtran(d(cq), d(cf), d(g["zm_mu"]), d(g["zm_md"]), d(g["zm_du"]), d(g["zm_eu"]), d(g["zm_ed"]), d(g["zm_dp"]), d(cdp),
+                      d(g["zm_jt"]), d(g["zm_maxg"]), d(g["zm_ideep"]), d(g["zm_lengath"]), cases.DOCONVTRAN, cases.ISDRY, synth.ZTODT)
+    assert_close("convtran.dqdt", ct.cpu().numpy(), g["ct_dqdt"])
 
 
 @pytest.mark.parametrize("name", cases.AERO_GOLDEN)
