@@ -2,7 +2,8 @@
 //
 //   geopotential_t   /root/reference/physics/geopotential.F90:153-310   bottom-up hydrostatic integration
 //   zm_conv_evap     /root/reference/physics/zm_conv.F90:1712-1972      top-down precipitation flux / evaporation
-//   momtran          /root/reference/physics/zm_conv.F90:2315-2715      up/down in-cloud wind recurrences
+//   convtran         /root/reference/physics/zm_conv.F90:1976-2311      tracer transport on the gathered columns
+//   (momtran lives in k_momtran.hip)
 //
 // HBM layout is column-contiguous [ncol][pver]; the scans are serial in k and independent across columns, so
 // the mapping is one lane per column with the block's columns staged through LDS:
@@ -238,143 +239,6 @@ __global__ __launch_bounds__(NT) void zm_conv_evap_kernel(ZmDev P, const double 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// momtran: initialisation of the full-layout outputs (:2429-2443), element-wise
-// ------------------------------------------------------------------------------------------------------
-__global__ void momtran_init_kernel(size_t n2, size_t n1, colphys_momtran_io io)
-{
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-        const double w = io.winds[i];
-        io.pguall[i] = 0.0; io.pgdall[i] = 0.0; io.dqdt[i] = 0.0; io.icwu[i] = w; io.icwd[i] = w;
-        if (i < n1) io.seten[i] = 0.0;
-    }
-}
-
-// momtran proper: one lane per GATHERED column; block = one wave handling up to 64 gathered rows.
-// Gathered rows are sparse (lengath <= pcols per chunk), so lanes map to (chunk, slot) pairs of a
-// chunk-aligned range; work profiles are private (the kernel touches ~10 % of the columns).
-template <int ML>
-__global__ __launch_bounds__(NT) void momtran_kernel(ZmDev P, int ncol, int pver, int pcols, double dt, colphys_momtran_io io)
-{
-    const int row = blockIdx.x * NT + threadIdx.x;           // gathered row index in the flat layout
-    if (row >= ncol) return;
-    const int ic = row / pcols, c0 = ic * pcols, slot = row - c0;
-    const int il2g = io.lengath[ic];
-    if (slot >= il2g) return;
-    const size_t L = (size_t)pver, F = (size_t)ncol * L;
-    const double mbsth = 1.e-15;
-
-    int ktm = pver, kbm = pver;                                                  // :2449-2454 (per chunk)
-    for (int i = 0; i < il2g; ++i) {
-        ktm = min(ktm, io.jt[c0 + i]);
-        kbm = min(kbm, io.mx[c0 + i]);
-    }
-    const size_t ii = (size_t)(c0 + io.ideep[row] - 1);
-    const double *mu = io.mu + row * L - 1, *md = io.md + row * L - 1, *du = io.du + row * L - 1,
-                 *eu = io.eu + row * L - 1, *ed = io.ed + row * L - 1, *dp = io.dp + row * L - 1;
-    const int mx = io.mx[row];
-
-    double cnst[ML], chat[ML], cond[ML], conu[ML], pgu[ML], pgd[ML];
-    double mflux[2][ML + 1], wind0[2][ML], windf[2][ML];
-    for (int m = 0; m < 2; ++m) {
-        for (int k = 0; k < ML; ++k) { wind0[m][k] = 0.0; windf[m][k] = 0.0; }
-        for (int k = 0; k < ML + 1; ++k) mflux[m][k] = 0.0;
-    }
-
-    for (int m = 0; m < 2; ++m) {
-        const double *qw = io.winds + m * F + ii * L - 1;
-        for (int k = 1; k <= pver; ++k) { cnst[k] = qw[k]; wind0[m][k] = cnst[k]; }           // :2461-2466
-        for (int k = 1; k <= pver; ++k) {                                                     // :2473-2488
-            const int km1 = max(1, k - 1);
-            chat[k] = 0.5 * (cnst[k] + cnst[km1]);
-            conu[k] = chat[k];
-            cond[k] = chat[k];
-        }
-        pgu[1] = 0.0;                                                                         // :2497-2499
-        pgd[1] = 0.0;
-        for (int k = 2; k <= pver - 1; ++k) {                                                 // :2501-2521
-            const int km1 = k - 1, kp1 = k + 1;
-            const double mududp = (mu[k] * (cnst[k] - cnst[km1]) / dp[km1] + mu[kp1] * (cnst[kp1] - cnst[k]) / dp[k]);
-            pgu[k] = -P.momcu * 0.5 * mududp;
-            const double mddudp = (md[k] * (cnst[k] - cnst[km1]) / dp[km1] + md[kp1] * (cnst[kp1] - cnst[k]) / dp[k]);
-            pgd[k] = -P.momcd * 0.5 * mddudp;
-        }
-        {                                                                                     // :2524-2535
-            const int k = pver, km1 = pver - 1;
-            const double mududp = mu[k] * (cnst[k] - cnst[km1]) / dp[km1];
-            pgu[k] = -P.momcu * mududp;
-            const double mddudp = md[k] * (cnst[k] - cnst[km1]) / dp[km1];
-            pgd[k] = -P.momcd * mddudp;
-        }
-        {                                                                                     // :2543-2558
-            const int k = 2, km1 = 1, kk = pver;
-            const double mupdudp = mu[kk] + du[kk] * dp[kk];
-            if (mupdudp > mbsth) conu[kk] = (+eu[kk] * cnst[kk] * dp[kk] + pgu[kk] * dp[kk]) / mupdudp;
-            // operator precedence of the reference kept as is (:2554)
-            if (md[k] < -mbsth) cond[k] = (-ed[km1] * cnst[km1] * dp[km1]) - pgd[km1] * dp[km1] / md[k];
-        }
-        for (int kk = pver - 1; kk >= 1; --kk) {                                              // :2563-2575
-            const int kkp1 = kk + 1;
-            const double mupdudp = mu[kk] + du[kk] * dp[kk];
-            if (mupdudp > mbsth)
-                conu[kk] = (mu[kkp1] * conu[kkp1] + eu[kk] * cnst[kk] * dp[kk] + pgu[kk] * dp[kk]) / mupdudp;
-        }
-        for (int k = 3; k <= pver; ++k) {                                                     // :2579-2589
-            const int km1 = k - 1;
-            if (md[k] < -mbsth)
-                cond[k] = (md[km1] * cond[km1] - ed[km1] * cnst[km1] * dp[km1] - pgd[km1] * dp[km1]) / md[k];
-        }
-        double *dq = io.dqdt + m * F + ii * L - 1, *pu = io.pguall + m * F + ii * L - 1,
-               *pd = io.pgdall + m * F + ii * L - 1, *iu = io.icwu + m * F + ii * L - 1, *id = io.icwd + m * F + ii * L - 1;
-        for (int k = 1; k <= pver; ++k) {
-            double dcondt = 0.0;
-            if (k >= ktm) {                                                                   // :2596-2611
-                const int kp1 = min(pver, k + 1);
-                dcondt = +(mu[kp1] * (conu[kp1] - chat[kp1]) - mu[k] * (conu[k] - chat[k])
-                           + md[kp1] * (cond[kp1] - chat[kp1]) - md[k] * (cond[k] - chat[k])) / dp[k];
-            }
-            if (k >= kbm && k == mx)                                                          // :2615-2627
-                dcondt = (1.0 / dp[k]) * (-mu[k] * (conu[k] - chat[k]) - md[k] * (cond[k] - chat[k]));
-            dq[k] = dcondt; pu[k] = -pgu[k]; pd[k] = -pgd[k]; iu[k] = conu[k]; id[k] = cond[k];   // :2632-2642
-        }
-        for (int k = ktm; k <= pver; ++k)                                                     // :2646-2653
-            mflux[m][k] = -mu[k] * (conu[k] - chat[k]) - md[k] * (cond[k] - chat[k]);
-        for (int k = ktm; k <= pver; ++k)                                                     // :2658-2666
-            windf[m][k] = cnst[k] - (mflux[m][k + 1] - mflux[m][k]) * dt / dp[k];
-    }
-    double *se = io.seten + ii * L - 1;
-    for (int k = ktm; k <= pver; ++k) {                                                       // :2675-2712
-        const int km1 = max(1, k - 1), kp1 = min(pver, k + 1);
-        const double utop = (wind0[0][k] + wind0[0][km1]) / 2.0, vtop = (wind0[1][k] + wind0[1][km1]) / 2.0;
-        const double ubot = (wind0[0][kp1] + wind0[0][k]) / 2.0, vbot = (wind0[1][kp1] + wind0[1][k]) / 2.0;
-        const double fket = utop * mflux[0][k] + vtop * mflux[1][k];
-        const double fkeb = ubot * mflux[0][k + 1] + vbot * mflux[1][k + 1];
-        const double ketend_cons = (fket - fkeb) / dp[k];
-        const double ketend = ((windf[0][k] * windf[0][k] + windf[1][k] * windf[1][k])
-                               - (wind0[0][k] * wind0[0][k] + wind0[1][k] * wind0[1][k])) * 0.5 / dt;
-        se[k] = ketend_cons - ketend;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// physics_update (tendency application part), element-wise, grid-stride
-// ------------------------------------------------------------------------------------------------------
-__global__ void physics_update_kernel(size_t n, double dt, double cpair, double qmin, const double *__restrict__ t_in,
-                                      const double *__restrict__ s_tend, double *t_out, const double *__restrict__ q_in,
-                                      const double *__restrict__ q_tend, double *q_out, const double *__restrict__ u_in,
-                                      const double *__restrict__ u_tend, double *u_out, const double *__restrict__ v_in,
-                                      const double *__restrict__ v_tend, double *v_out)
-{
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if (t_out) t_out[i] = t_in[i] + s_tend[i] * dt / cpair;            // physics_types.F90:427
-        if (q_out) q_out[i] = fmax(q_in[i] + q_tend[i] * dt, qmin);       // :321, qneg3 :329
-        if (u_out) u_out[i] = u_in[i] + u_tend[i] * dt;                   // :295
-        if (v_out) v_out[i] = v_in[i] + v_tend[i] * dt;                   // :303
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
 // convtran :1976-2311 (non-microphysics path): one lane per (gathered column, tracer)
 //   grid.y = tracer m (1-based m+1 = 2..ncnst in the reference); tracers with doconvtran = 0 are skipped on the host.
 // ------------------------------------------------------------------------------------------------------
@@ -479,6 +343,24 @@ __global__ __launch_bounds__(NT) void convtran_kernel(int ncol, int pver, int pc
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// physics_update (tendency application part), element-wise, grid-stride
+// ------------------------------------------------------------------------------------------------------
+__global__ void physics_update_kernel(size_t n, double dt, double cpair, double qmin, const double *__restrict__ t_in,
+                                      const double *__restrict__ s_tend, double *t_out, const double *__restrict__ q_in,
+                                      const double *__restrict__ q_tend, double *q_out, const double *__restrict__ u_in,
+                                      const double *__restrict__ u_tend, double *u_out, const double *__restrict__ v_in,
+                                      const double *__restrict__ v_tend, double *v_out)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (t_out) t_out[i] = t_in[i] + s_tend[i] * dt / cpair;            // physics_types.F90:427
+        if (q_out) q_out[i] = fmax(q_in[i] + q_tend[i] * dt, qmin);       // :321, qneg3 :329
+        if (u_out) u_out[i] = u_in[i] + u_tend[i] * dt;                   // :295
+        if (v_out) v_out[i] = v_in[i] + v_tend[i] * dt;                   // :303
+    }
+}
+
 inline int set_lds(const void *fn, size_t bytes)
 {
     if (bytes > 64 * 1024)
@@ -512,21 +394,6 @@ int launch_zm_conv_evap(const ZmDev &P, const double *estbl_dev, int ncol, int p
     if (set_lds((const void *)zm_conv_evap_kernel, lds)) return COLPHYS_ERR_HIP;
     const int nblk = (ncol + TILE - 1) / TILE;
     hipLaunchKernelGGL(zm_conv_evap_kernel, dim3(nblk), dim3(NT), lds, st, P, estbl_dev, ncol, pver, deltat, io);
-    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
-}
-
-int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, const colphys_momtran_io &io, hipStream_t st)
-{
-    const size_t n1 = (size_t)ncol * pver, n2 = 2 * n1;
-    const int iblk = (int)((n2 + 255) / 256 < 2048 ? (n2 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(momtran_init_kernel, dim3(iblk), dim3(256), 0, st, n2, n1, io);
-    const int nblk = (ncol + NT - 1) / NT;
-    if (pver <= 32)
-        hipLaunchKernelGGL(momtran_kernel<36>, dim3(nblk), dim3(NT), 0, st, P, ncol, pver, pcols, dt, io);
-    else if (pver <= 72)
-        hipLaunchKernelGGL(momtran_kernel<76>, dim3(nblk), dim3(NT), 0, st, P, ncol, pver, pcols, dt, io);
-    else
-        hipLaunchKernelGGL(momtran_kernel<COLPHYS_MAX_PVER + 4>, dim3(nblk), dim3(NT), 0, st, P, ncol, pver, pcols, dt, io);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
 
