@@ -73,7 +73,7 @@ struct Carver {
 
 size_t zm_ws_bytes(int ncol, int pver)
 {
-    return 256 * 20 + sizeof(int) * (size_t)ncol * 6 + sizeof(double) * (size_t)ncol * 3 + sizeof(double) * (size_t)ncol * pver * 6 + 4096;
+    return 256 * 32 + sizeof(int) * (size_t)ncol * 10 + sizeof(double) * (size_t)ncol * 6 + sizeof(double) * (size_t)ncol * pver * 8 + 4096;
 }
 ZmWorkspace zm_ws_carve(void *base, int ncol, int pver)
 {
@@ -87,6 +87,9 @@ ZmWorkspace zm_ws_carve(void *base, int ncol, int pver)
     const size_t n = (size_t)ncol * pver;
     w.mu_f = c.take<double>(n); w.md_f = c.take<double>(n); w.du_f = c.take<double>(n);
     w.eu_f = c.take<double>(n); w.ed_f = c.take<double>(n); w.dp_f = c.take<double>(n);
+    w.dmpdz2 = c.take<double>(ncol); w.cape2 = c.take<double>(ncol); w.tl2 = c.take<double>(ncol);
+    w.lcl2 = c.take<int>(ncol); w.lel2 = c.take<int>(ncol); w.mx2 = c.take<int>(ncol); w.retrig = c.take<int>(ncol);
+    w.tp2 = c.take<double>(n); w.qstp2 = c.take<double>(n);
     return w;
 }
 
@@ -426,6 +429,29 @@ int colphys_aero_tables_set(const colphys_aero_tables *tb)
     bad |= up(tb->crefwsw, 8 * nsw * 2, (const void **)&A.crefwsw);
     bad |= up(tb->crefwlw, 8 * nlw * 2, (const void **)&A.crefwlw);
     if (bad) return fail(COLPHYS_ERR_HIP, "uploading aerosol tables failed (null table or hipMalloc)");
+    // packed slices (see AeroDev): table element (m, ib, ii, ir, nc) -> slice[t][(ii*PREFR + ir)*AERO_NCP + nc]
+    auto pack = [&](int ntab, const double *const *tabs, const double *refr, const double *refi, size_t nbnd,
+                    const double **dst) -> int {
+        const size_t sl = (size_t)aero_slice_doubles(ntab), corners = (size_t)COLPHYS_PREFI * COLPHYS_PREFR;
+        std::vector<double> h(nm * nbnd * sl, 0.0);
+        for (size_t u = 0; u < nm * nbnd; ++u) {
+            double *o = h.data() + u * sl;
+            for (int t = 0; t < ntab; ++t)
+                for (size_t c = 0; c < corners; ++c)
+                    for (int nc = 0; nc < COLPHYS_NCOEF; ++nc)
+                        o[(size_t)t * AERO_TBLP + c * AERO_NCP + nc] = tabs[t][u * tblsz + c * COLPHYS_NCOEF + nc];
+            double *g = o + (size_t)ntab * AERO_TBLP;
+            for (int j = 0; j < COLPHYS_PREFR; ++j) g[j] = refr[u * COLPHYS_PREFR + j];
+            for (int j = 0; j < COLPHYS_PREFI; ++j) g[COLPHYS_PREFR + j] = refi[u * COLPHYS_PREFI + j];
+        }
+        return up(h.data(), h.size() * sizeof(double), (const void **)dst);
+    };
+    {
+        const double *sw_t[3] = {tb->extpsw, tb->abspsw, tb->asmpsw}, *lw_t[1] = {tb->absplw};
+        bad |= pack(3, sw_t, tb->refrtabsw, tb->refitabsw, nsw, &A.slices_sw);
+        bad |= pack(1, lw_t, tb->refrtablw, tb->refitablw, nlw, &A.slices_lw);
+    }
+    if (bad) return fail(COLPHYS_ERR_HIP, "uploading packed aerosol table slices failed");
     g_aero_set = true;
     return COLPHYS_OK;
 }

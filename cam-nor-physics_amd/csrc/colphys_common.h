@@ -35,7 +35,16 @@ struct AeroDev {
     const int *nspec, *spectype;
     const double *sigmag, *specdens, *hygro, *specrefindex_sw, *specrefindex_lw;
     const double *refrtabsw, *refitabsw, *refrtablw, *refitablw, *extpsw, *abspsw, *asmpsw, *absplw, *crefwsw, *crefwlw;
+    // packed per-(mode, band) table slices = the LDS image the optics kernels stage (built by colphys_aero_tables_set):
+    // ntab x [PREFI*PREFR corners][AERO_NCP] coefficients (5 + zero pad), refr[PREFR], refi[PREFI], zero fill to 1 KiB
+    const double *slices_sw, *slices_lw;
 };
+constexpr int AERO_NCP = 6;
+constexpr int AERO_TBLP = COLPHYS_PREFI * COLPHYS_PREFR * AERO_NCP;
+constexpr int aero_slice_doubles(int ntab)
+{
+    return ((ntab * AERO_TBLP + COLPHYS_PREFR + COLPHYS_PREFI) * 8 + 1023) / 1024 * 128;
+}
 
 // ---- saturation vapour pressure: Goff-Gratch over water / ice (spec: oracle/stubs/l0_arithmetic.F90) ----
 __device__ inline double svp_water_gg(double t)
@@ -62,6 +71,10 @@ struct ZmWorkspace {            // device scratch owned by the API layer (grow-o
     int *jt_f, *maxg_f;         // [ncol] full-layout copies
     double *dsub_f;             // [ncol]
     double *mu_f, *md_f, *du_f, *eu_f, *ed_f, *dp_f;  // [ncol][pver] full-layout plume profiles
+    // second ascent of the first-pass triggered columns (zm_ascent2_kernel -> zm_plume2_kernel)
+    double *dmpdz2, *cape2, *tl2;   // [ncol]
+    int *lcl2, *lel2, *mx2, *retrig; // [ncol]
+    double *tp2, *qstp2;            // [ncol][pver]
 };
 int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io &io,
                     const ZmWorkspace &ws, hipStream_t st, hipEvent_t *ev /* 4 events or null */);

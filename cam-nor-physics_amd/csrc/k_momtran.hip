@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NT) void momtran_wave_kernel(ZmDev P, int ncol, int
     __syncthreads();
 
     for (int m = 0; m < 2; ++m) {
-        const double *cn = s_c + m * LD, *chat = s_chat + m * LD, *conu = s_conu + m * LD, *cond = s_cond + m * LD;
+        const double *chat = s_chat + m * LD, *conu = s_conu + m * LD, *cond = s_cond + m * LD;
         double *mf = s_mf + m * LD;
         for (int k = lane + 1; k <= pver; k += NT) {
             double dcondt = 0.0;

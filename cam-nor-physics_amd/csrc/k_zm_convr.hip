@@ -475,68 +475,119 @@ __global__ __launch_bounds__(WAVE) void zm_trigger_kernel(ZmDev P, int ncol, int
 }
 
 // ------------------------------------------------------------------------------------------------------
-// cldprp :3024-4026 (non-microphysics path), one column, private work profiles
+// Plume ensemble on ONE WAVE PER COLUMN (cldprp :3024-4026, closure :4028-4260, q1q2_pjr :4262-4421).
+//
+// Only the triggered columns (~10 %) get here, so a lane-per-column mapping leaves the machine almost empty
+// (80 waves) and each lane drags ~50 private work profiles through scratch.  Instead every triggered column
+// gets its own wave, the work profiles live in LDS (49 x (pver+2) doubles = 13 KB at L32), and
+//   * loops that are element-wise in k run one level per lane            (PAR),
+//   * the genuine recurrences / searches / running sums run in the reference's order, redundantly on all
+//     lanes (uniform control flow: in SIMT that costs exactly what one lane would), reading and writing LDS.
+// A barrier separates a PAR phase from whatever reads its neighbours' levels.  Same arithmetic, same order.
 // ------------------------------------------------------------------------------------------------------
-template <int ML>
-struct CldOut {
-    double mu[ML], eu[ML], du[ML], md[ML], ed[ML], sd[ML], qd[ML], mc[ML], qu[ML], su[ML], qst[ML], ql[ML],
-        cmeg[ML], pflx[ML], evp[ML], cu[ML], rprd[ML], qcde[ML];
-    int jt, jlcl, j0, jd;
+#define PAR(k, lo, hi) for (int k = (lo) + lane; k <= (hi); k += WAVE)
+#define SYNC() __syncthreads()
+
+constexpr int PLUME_NARR = 49;
+
+struct PlumeLds {
+    double *q, *t, *p, *z, *s, *zf, *shat, *qhat, *dp, *tp, *qstp;
+    double *mu, *eu, *du, *md, *ed, *sd, *qd, *mc, *qu, *su, *qst, *ql, *cmeg, *pflx, *evp, *cu, *rprd, *qcde;
+    double *gamma, *dz, *hu, *hd, *eps, *f, *k1, *i2, *i3, *i4, *qsthat, *hsthat, *gamhat, *qds, *mcp, *mrl, *tu, *td, *hmn,
+        *hsat;
+    __device__ void carve(double *base, int LD)
+    {
+        double **slots[] = {&q, &t, &p, &z, &s, &zf, &shat, &qhat, &dp, &tp, &qstp, &mu, &eu, &du, &md, &ed, &sd, &qd, &mc, &qu,
+                            &su, &qst, &ql, &cmeg, &pflx, &evp, &cu, &rprd, &qcde, &gamma, &dz, &hu, &hd, &eps, &f, &k1, &i2, &i3,
+                            &i4, &qsthat, &hsthat, &gamhat, &qds, &mcp, &mrl, &tu, &td, &hmn, &hsat};
+        int n = 0;
+        for (double **sl : slots) { *sl = base + (size_t)n * LD; ++n; }
+    }
 };
 
-template <int ML>
-__device__ void cldprp_d(const ZmDev &P, int pver, int msg, const double *q, const double *t, const double *p,
-                         const double *z, const double *s, const double *zf, const double *shat, const double *qhat,
-                         int jb, int lel, double landfrac, CldOut<ML> &o)
+struct PlumeIdx { int jt, jlcl, j0, jd; };
+
+// column inputs -> LDS (:825-860, 926-940) and the interface values shat / qhat (:1007-1027)
+__device__ void plume_load(const ZmDev &P, const ColIn &c, const PlumeLds &A, int lane)
 {
-    double gamma[ML], dz[ML], hu[ML], hd[ML], eps[ML], f[ML], k1[ML], i2[ML], i3[ML], i4[ML], qsthat[ML], hsthat[ML],
-        gamhat[ML], qds[ML], mcp[ML], mrl[ML], tu[ML], td[ML], hmn[ML], hsat[ML];
-    double hmin, expdif = 0.0, expnum, ftemp, eps0, rmue, zuef, zdef, epsm = 0.0, ratmjb, est, totpcp, totevp, ql1,
-           estu, qstu, mdt;
+    const int pver = c.pver, msg = c.msg;
+    PAR(k, 1, pver) {
+        const double qk = c.Q(k), tk = c.T(k), zk = c.Z(k);
+        A.q[k] = qk; A.t[k] = tk; A.p[k] = c.Pm(k); A.z[k] = zk; A.zf[k] = c.Zf(k);
+        const double sk = tk + (P.grav / ((1.0 + P.zvir * qk) * P.cpres)) * zk;
+        A.s[k] = sk; A.shat[k] = sk; A.qhat[k] = qk;
+        A.dp[k] = 0.01 * c.dpp[k];
+    }
+    if (lane == 0) A.zf[pver + 1] = c.Zf(pver + 1);
+    SYNC();
+    PAR(k, msg + 2, pver) {
+        const double sg = A.s[k], sgm = A.s[k - 1], qg = A.q[k], qgm = A.q[k - 1];
+        double sdifr = 0.0, qdifr = 0.0;
+        if (sg > 0.0 || sgm > 0.0) sdifr = fabs((sg - sgm) / fmax(sgm, sg));
+        if (qg > 0.0 || qgm > 0.0) qdifr = fabs((qg - qgm) / fmax(qgm, qg));
+        if (sdifr > 1.E-6) A.shat[k] = log(sgm / sg) * sgm * sg / (sgm - sg);
+        else A.shat[k] = 0.5 * (sg + sgm);
+        if (qdifr > 1.E-6) A.qhat[k] = log(qgm / qg) * qgm * qg / (qgm - qg);
+        else A.qhat[k] = 0.5 * (qg + qgm);
+    }
+    SYNC();
+}
+
+// cldprp :3024-4026 (non-microphysics path)
+__device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, int jb, int lel, double landfrac, int lane,
+                         PlumeIdx &o)
+{
     const int mx = jb;
     const double rd = P.rgas, grav = P.grav, cp = P.cp, rl = P.rl, dcol = P.dcol, eps1 = P.eps1;
     const double zvir = P.zvir, cpvir = P.cpvir, tmelt = P.tmelt;
     const double small = 1.e-20;
+    double hmin, expdif = 0.0, eps0, epsm = 0.0, totpcp = 0.0, totevp = 0.0, mdt;
 
     const double c0mask = P.c0_ocn * (1.0 - landfrac) + P.c0_lnd * landfrac;                 // :3239-3240
     const double tiedke_msk = P.tiedke_add * (1.0 - landfrac) + P.tiedke_lnd * landfrac;
 
-    for (int k = 1; k <= pver; ++k) dz[k] = zf[k] - zf[k + 1];
-
-    for (int k = 1; k <= pver; ++k) {                                                        // :3256-3314
-        k1[k] = 0.0; i2[k] = 0.0; i3[k] = 0.0; i4[k] = 0.0;
-        o.mu[k] = 0.0; f[k] = 0.0; eps[k] = 0.0; o.eu[k] = 0.0; o.du[k] = 0.0; o.ql[k] = 0.0; o.cu[k] = 0.0;
-        o.evp[k] = 0.0; o.cmeg[k] = 0.0; qds[k] = q[k]; o.md[k] = 0.0; o.ed[k] = 0.0; o.sd[k] = s[k];
-        o.qd[k] = q[k]; o.mc[k] = 0.0; o.qu[k] = q[k]; o.su[k] = s[k];
-        qsat_hPa(P, t[k], p[k], est, o.qst[k]);
-        if (p[k] - est <= 0.0) o.qst[k] = 1.0;
-        const double mrd = (1.0 + zvir * q[k]) * rd;
-        mcp[k] = (1.0 + cpvir * q[k]) * cp;
-        mrl[k] = (1.0 - dcol * (t[k] - tmelt)) * rl;
-        gamma[k] = o.qst[k] * (1.0 + o.qst[k] / eps1) * eps1 * mrl[k] / (mrd * (t[k] * t[k])) * mrl[k] / mcp[k];
-        hmn[k] = mcp[k] * t[k] + grav * z[k] + mrl[k] * q[k];
-        hsat[k] = mcp[k] * t[k] + grav * z[k] + mrl[k] * o.qst[k];
-        hu[k] = hmn[k];
-        hd[k] = hmn[k];
-        o.rprd[k] = 0.0;
-        o.qcde[k] = 0.0;
-        td[k] = (hd[k] - grav * zf[k] - (1.0 + dcol * tmelt) * rl * qds[k]) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * qds[k]));
-        tu[k] = 0.0;
+    PAR(k, 1, pver) {                                                                        // :3245-3314
+        const double qk = A.q[k], tk = A.t[k], pk = A.p[k], sk = A.s[k];
+        A.dz[k] = A.zf[k] - A.zf[k + 1];
+        A.k1[k] = 0.0; A.i2[k] = 0.0; A.i3[k] = 0.0; A.i4[k] = 0.0;
+        A.mu[k] = 0.0; A.f[k] = 0.0; A.eps[k] = 0.0; A.eu[k] = 0.0; A.du[k] = 0.0; A.ql[k] = 0.0; A.cu[k] = 0.0;
+        A.evp[k] = 0.0; A.cmeg[k] = 0.0; A.qds[k] = qk; A.md[k] = 0.0; A.ed[k] = 0.0; A.sd[k] = sk;
+        A.qd[k] = qk; A.mc[k] = 0.0; A.qu[k] = qk; A.su[k] = sk;
+        double est, qst;
+        qsat_hPa(P, tk, pk, est, qst);
+        if (pk - est <= 0.0) qst = 1.0;
+        A.qst[k] = qst;
+        const double mrd = (1.0 + zvir * qk) * rd;
+        const double mcp = (1.0 + cpvir * qk) * cp;
+        const double mrl = (1.0 - dcol * (tk - tmelt)) * rl;
+        A.mcp[k] = mcp; A.mrl[k] = mrl;
+        A.gamma[k] = qst * (1.0 + qst / eps1) * eps1 * mrl / (mrd * (tk * tk)) * mrl / mcp;
+        const double hmn = mcp * tk + grav * A.z[k] + mrl * qk;
+        A.hmn[k] = hmn;
+        A.hsat[k] = mcp * tk + grav * A.z[k] + mrl * qst;
+        A.hu[k] = hmn;
+        A.hd[k] = hmn;
+        A.rprd[k] = 0.0;
+        A.qcde[k] = 0.0;
+        A.td[k] = (hmn - grav * A.zf[k] - (1.0 + dcol * tmelt) * rl * qk) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * qk));
+        A.tu[k] = 0.0;
     }
-    for (int k = 1; k <= msg + 1; ++k) { hsthat[k] = hsat[k]; qsthat[k] = o.qst[k]; gamhat[k] = gamma[k]; }   // :3349-3355
-    totpcp = 0.0;
-    totevp = 0.0;
-    for (int k = msg + 2; k <= pver; ++k) {                                                  // :3360-3378
-        if (fabs(o.qst[k - 1] - o.qst[k]) > 1.E-6)
-            qsthat[k] = log(o.qst[k - 1] / o.qst[k]) * o.qst[k - 1] * o.qst[k] / (o.qst[k - 1] - o.qst[k]);
-        else
-            qsthat[k] = o.qst[k];
-        hsthat[k] = mcp[k] * shat[k] + mrl[k] * qsthat[k];
-        if (fabs(gamma[k - 1] - gamma[k]) > 1.E-6)
-            gamhat[k] = log(gamma[k - 1] / gamma[k]) * gamma[k - 1] * gamma[k] / (gamma[k - 1] - gamma[k]);
-        else
-            gamhat[k] = gamma[k];
+    SYNC();
+    PAR(k, 1, pver) {                                                                        // :3349-3378
+        if (k <= msg + 1) {
+            A.hsthat[k] = A.hsat[k]; A.qsthat[k] = A.qst[k]; A.gamhat[k] = A.gamma[k];
+        } else {
+            const double qa = A.qst[k - 1], qb = A.qst[k], ga = A.gamma[k - 1], gb = A.gamma[k];
+            double qsthat;
+            if (fabs(qa - qb) > 1.E-6) qsthat = log(qa / qb) * qa * qb / (qa - qb);
+            else qsthat = qb;
+            A.qsthat[k] = qsthat;
+            A.hsthat[k] = A.mcp[k] * A.shat[k] + A.mrl[k] * qsthat;
+            if (fabs(ga - gb) > 1.E-6) A.gamhat[k] = log(ga / gb) * ga * gb / (ga - gb);
+            else A.gamhat[k] = gb;
+        }
     }
+    SYNC();
 
     o.jt = max(lel, P.limcnv + 1);                                                           // :3383-3390
     o.jt = min(o.jt, pver);
@@ -544,163 +595,223 @@ __device__ void cldprp_d(const ZmDev &P, int pver, int msg, const double *q, con
     o.jlcl = lel;
     hmin = 1.E6;
     o.j0 = pver;
-    for (int k = msg + 1; k <= pver; ++k)                                                    // :3395-3402
-        if (hsat[k] <= hmin && k >= o.jt && k <= jb) { hmin = hsat[k]; o.j0 = k; }
+    for (int k = msg + 1; k <= pver; ++k) {                                                  // :3395-3402
+        const double h = A.hsat[k];
+        if (h <= hmin && k >= o.jt && k <= jb) { hmin = h; o.j0 = k; }
+    }
     o.j0 = min(o.j0, jb - 2);                                                                // :3404-3409
     o.j0 = max(o.j0, o.jt + 2);
     o.j0 = min(o.j0, pver);
 
-    for (int k = msg + 1; k <= pver; ++k) {                                                  // :3414-3424
+    const double hmn_mx = A.hmn[mx], s_mx = A.s[mx];
+    PAR(k, msg + 1, pver) {                                                                  // :3414-3424
         if (k >= o.jt && k <= jb) {
-            hu[k] = hmn[mx] + cp * tiedke_msk;
-            o.su[k] = s[mx] + tiedke_msk / (1.0 + cpvir * o.qu[k]);
+            A.hu[k] = hmn_mx + cp * tiedke_msk;
+            A.su[k] = s_mx + tiedke_msk / (1.0 + cpvir * A.qu[k]);
         }
     }
-    for (int k = pver - 1; k >= msg + 1; --k) {                                              // :3430-3442
-        if (k < jb && k >= o.jt) {
-            k1[k] = k1[k + 1] + (hmn[mx] - hmn[k]) * dz[k];
-            const double ihat = 0.5 * (k1[k + 1] + k1[k]);
-            i2[k] = i2[k + 1] + ihat * dz[k];
-            const double idag = 0.5 * (i2[k + 1] + i2[k]);
-            i3[k] = i3[k + 1] + idag * dz[k];
-            const double iprm = 0.5 * (i3[k + 1] + i3[k]);
-            i4[k] = i4[k + 1] + iprm * dz[k];
+    {                                                                                        // :3430-3442 prefix sums
+        double k1p = 0.0, i2p = 0.0, i3p = 0.0, i4p = 0.0;     // values at k+1 (all zero at pver)
+        for (int k = pver - 1; k >= msg + 1; --k) {
+            if (k < jb && k >= o.jt) {
+                const double dzk = A.dz[k];
+                const double k1k = k1p + (hmn_mx - A.hmn[k]) * dzk;
+                const double ihat = 0.5 * (k1p + k1k);
+                const double i2k = i2p + ihat * dzk;
+                const double idag = 0.5 * (i2p + i2k);
+                const double i3k = i3p + idag * dzk;
+                const double iprm = 0.5 * (i3p + i3k);
+                const double i4k = i4p + iprm * dzk;
+                A.k1[k] = k1k; A.i2[k] = i2k; A.i3[k] = i3k; A.i4[k] = i4k;
+                k1p = k1k; i2p = i2k; i3p = i3k; i4p = i4k;
+            } else {
+                k1p = 0.0; i2p = 0.0; i3p = 0.0; i4p = 0.0;     // untouched levels hold their initial zeros
+            }
         }
     }
     hmin = 1.E6;                                                                             // :3446-3456
     for (int k = msg + 1; k <= pver; ++k) {
-        if (k >= o.j0 && k <= jb && hmn[k] <= hmin) {
-            hmin = hmn[k];
-            expdif = hmn[mx] - hmin;
+        const double h = A.hmn[k];
+        if (k >= o.j0 && k <= jb && h <= hmin) {
+            hmin = h;
+            expdif = hmn_mx - hmin;
         }
     }
-    for (int k = msg + 2; k <= pver; ++k) {                                                  // :3462-3487
-        expnum = 0.0;
-        ftemp = 0.0;
+    SYNC();
+    PAR(k, msg + 2, pver) {                                                                  // :3462-3487
+        double expnum = 0.0;
+        double k1k = A.k1[k];
         if (k < o.jt || k >= jb) {
-            k1[k] = 0.0;
-            expnum = 0.0;
+            k1k = 0.0;
+            A.k1[k] = 0.0;
         } else {
-            expnum = hmn[mx] - (hsat[k - 1] * (zf[k] - z[k]) + hsat[k] * (z[k - 1] - zf[k])) / (z[k - 1] - z[k]);
+            expnum = hmn_mx - (A.hsat[k - 1] * (A.zf[k] - A.z[k]) + A.hsat[k] * (A.z[k - 1] - A.zf[k])) / (A.z[k - 1] - A.z[k]);
         }
-        if ((expdif > 100.0 && expnum > 0.0) && k1[k] > expnum * dz[k]) {
-            ftemp = expnum / k1[k];
+        if ((expdif > 100.0 && expnum > 0.0) && k1k > expnum * A.dz[k]) {
+            const double i2k = A.i2[k], i3k = A.i3[k], i4k = A.i4[k];
+            const double ftemp = expnum / k1k;
             const double ft2 = ftemp * ftemp, ft3 = ft2 * ftemp, ft4 = ft2 * ft2;
-            const double i2sq = i2[k] * i2[k], i2cu = i2sq * i2[k];
-            const double k1sq = k1[k] * k1[k], k1cu = k1sq * k1[k];
-            f[k] = ftemp + i2[k] / k1[k] * ft2 + (2.0 * i2sq - k1[k] * i3[k]) / k1sq * ft3
-                   + (-5.0 * k1[k] * i2[k] * i3[k] + 5.0 * i2cu + k1sq * i4[k]) / k1cu * ft4;
-            f[k] = fmax(f[k], 0.0);
-            f[k] = fmin(f[k], P.entrmn);
+            const double i2sq = i2k * i2k, i2cu = i2sq * i2k;
+            const double k1sq = k1k * k1k, k1cu = k1sq * k1k;
+            double fk = ftemp + i2k / k1k * ft2 + (2.0 * i2sq - k1k * i3k) / k1sq * ft3
+                        + (-5.0 * k1k * i2k * i3k + 5.0 * i2cu + k1sq * i4k) / k1cu * ft4;
+            fk = fmax(fk, 0.0);
+            fk = fmin(fk, P.entrmn);
+            A.f[k] = fk;
         }
     }
+    SYNC();
     if (o.j0 < jb) {                                                                         // :3488-3492
-        if (f[o.j0] < 1.E-6 && f[o.j0 + 1] > f[o.j0]) o.j0 = o.j0 + 1;
+        if (A.f[o.j0] < 1.E-6 && A.f[o.j0 + 1] > A.f[o.j0]) o.j0 = o.j0 + 1;
     }
-    for (int k = msg + 2; k <= pver; ++k)                                                    // :3493-3499
-        if (k >= o.jt && k <= o.j0) f[k] = fmax(f[k], f[k - 1]);
-    eps0 = f[o.j0];                                                                          // :3500-3503
-    eps[jb] = eps0;
-    for (int k = pver; k >= msg + 1; --k)                                                    // :3507-3518
-        if (k >= o.j0 && k <= jb) eps[k] = f[o.j0];
-    for (int k = pver; k >= msg + 1; --k)
-        if (k < o.j0 && k >= o.jt) eps[k] = f[k];
+    for (int k = msg + 2; k <= pver; ++k)                                                    // :3493-3499 running max
+        if (k >= o.jt && k <= o.j0) A.f[k] = fmax(A.f[k], A.f[k - 1]);
+    eps0 = A.f[o.j0];                                                                        // :3500-3503
+    const double f_j0 = eps0;
+    PAR(k, msg + 1, pver) {                                                                  // :3502-3518
+        if (k >= o.j0 && k <= jb) A.eps[k] = f_j0;
+        else if (k < o.j0 && k >= o.jt) A.eps[k] = A.f[k];
+        else if (k == jb) A.eps[k] = eps0;
+    }
+    SYNC();
 
-    if (eps0 > 0.0) {                                                                        // :3550-3554
-        o.mu[jb] = 1.0;
-        o.eu[jb] = o.mu[jb] / dz[jb];
-    }
     const int tmplel = o.jt;                                                                 // :3558
-    for (int k = pver; k >= msg + 1; --k) {                                                  // :3561-3571
-        if (eps0 > 0.0 && (k >= tmplel && k < jb)) {
-            zuef = zf[k] - zf[jb];
-            rmue = (1.0 / eps0) * (exp(eps[k + 1] * zuef) - 1.0) / zuef;
-            o.mu[k] = (1.0 / eps0) * (exp(eps[k] * zuef) - 1.0) / zuef;
-            o.eu[k] = (rmue - o.mu[k + 1]) / dz[k];
-            o.du[k] = (rmue - o.mu[k]) / dz[k];
-        }
-    }
-    for (int k = jb - 1; k >= lel; --k) {                                                    // :3579-3598
+    const double zf_jb = A.zf[jb];
+    PAR(k, msg + 1, pver) {                                                                  // :3550-3571, mu first
         if (eps0 > 0.0) {
-            if (o.mu[k] < 0.02) {
-                hu[k] = hmn[k];
-                o.mu[k] = 0.0;
-                o.eu[k] = 0.0;
-                o.du[k] = o.mu[k + 1] / dz[k];
+            if (k == jb) A.mu[k] = 1.0;
+            else if (k >= tmplel && k < jb) {
+                const double zuef = A.zf[k] - zf_jb;
+                A.mu[k] = (1.0 / eps0) * (exp(A.eps[k] * zuef) - 1.0) / zuef;
+            }
+        }
+    }
+    SYNC();
+    PAR(k, msg + 1, pver) {                                                                  // ... then eu, du
+        if (eps0 > 0.0) {
+            if (k == jb) A.eu[k] = A.mu[k] / A.dz[k];
+            else if (k >= tmplel && k < jb) {
+                const double zuef = A.zf[k] - zf_jb;
+                const double rmue = (1.0 / eps0) * (exp(A.eps[k + 1] * zuef) - 1.0) / zuef;
+                A.eu[k] = (rmue - A.mu[k + 1]) / A.dz[k];
+                A.du[k] = (rmue - A.mu[k]) / A.dz[k];
+            }
+        }
+    }
+    SYNC();
+    if (eps0 > 0.0) {                                                                        // :3579-3598
+        double hu_kp1 = A.hu[jb], mu_kp1 = A.mu[jb];            // carried in registers down the recurrence
+        for (int k = jb - 1; k >= lel; --k) {
+            const double muk = A.mu[k];
+            if (muk < 0.02) {
+                hu_kp1 = A.hmn[k];
+                A.hu[k] = hu_kp1;
+                A.mu[k] = 0.0;
+                A.eu[k] = 0.0;
+                A.du[k] = mu_kp1 / A.dz[k];
+                mu_kp1 = 0.0;
             } else {
-                hu[k] = o.mu[k + 1] / o.mu[k] * hu[k + 1] + dz[k] / o.mu[k] * (o.eu[k] * hmn[k] - o.du[k] * hsat[k]);
+                hu_kp1 = mu_kp1 / muk * hu_kp1 + A.dz[k] / muk * (A.eu[k] * A.hmn[k] - A.du[k] * A.hsat[k]);
+                A.hu[k] = hu_kp1;
+                mu_kp1 = muk;
             }
         }
     }
-    bool doit = true;                                                                        // :3603-3628
-    for (int k = jb - 2; k >= lel - 1; --k) {
-        if (doit && k >= 1) {
-            if (hu[k] <= hsthat[k] && hu[k + 1] > hsthat[k + 1] && o.mu[k] >= 0.02) {
-                if (hu[k] - hsthat[k] < -2000.0) { o.jt = k + 1; doit = false; }
-                else { o.jt = k; doit = false; }
-            } else if ((hu[k] > hu[jb]) || o.mu[k] < 0.02) {           // totfrz == 0 without microphysics
-                o.jt = k + 1;
-                doit = false;
+    {
+        bool doit = true;                                                                    // :3603-3628
+        const double hu_jb = A.hu[jb];
+        for (int k = jb - 2; k >= lel - 1; --k) {
+            if (doit && k >= 1) {
+                const double huk = A.hu[k], muk = A.mu[k];
+                if (huk <= A.hsthat[k] && A.hu[k + 1] > A.hsthat[k + 1] && muk >= 0.02) {
+                    if (huk - A.hsthat[k] < -2000.0) { o.jt = k + 1; doit = false; }
+                    else { o.jt = k; doit = false; }
+                } else if ((huk > hu_jb) || muk < 0.02) {          // totfrz == 0 without microphysics
+                    o.jt = k + 1;
+                    doit = false;
+                }
             }
         }
     }
-    for (int k = pver; k >= msg + 1; --k) {                                                  // :3632-3646
-        if (k >= lel && k <= o.jt && eps0 > 0.0) { o.mu[k] = 0.0; o.eu[k] = 0.0; o.du[k] = 0.0; hu[k] = hmn[k]; }
-        if (k == o.jt && eps0 > 0.0) {
-            o.du[k] = o.mu[k + 1] / dz[k];
-            o.eu[k] = 0.0;
-            o.mu[k] = 0.0;
+    {                                                                                        // :3632-3646
+        const double mu_jtp1 = (o.jt + 1 <= pver) ? A.mu[o.jt + 1] : 0.0;
+        SYNC();
+        PAR(k, msg + 1, pver) {
+            if (k >= lel && k <= o.jt && eps0 > 0.0) { A.mu[k] = 0.0; A.eu[k] = 0.0; A.du[k] = 0.0; A.hu[k] = A.hmn[k]; }
+            if (k == o.jt && eps0 > 0.0) {
+                A.du[k] = mu_jtp1 / A.dz[k];
+                A.eu[k] = 0.0;
+                A.mu[k] = 0.0;
+            }
         }
     }
-    for (int k = pver; k >= msg + 2; --k)                                                    // :3649-3654
-        tu[k] = (hu[k] - grav * zf[k] - (1.0 + dcol * tmelt) * rl * o.qu[k]) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * o.qu[k]));
-
+    SYNC();
+    PAR(k, msg + 2, pver) {                                                                  // :3649-3654
+        A.tu[k] = (A.hu[k] - grav * A.zf[k] - (1.0 + dcol * tmelt) * rl * A.qu[k]) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * A.qu[k]));
+    }
+    SYNC();
     for (int k = pver; k >= msg + 2; --k) {                                                  // :3656-3692
         if (k == jb && eps0 > 0.0) {
-            o.qu[k] = q[mx];
-            tu[k] = (hu[k] - grav * zf[k] - (1.0 + dcol * tmelt) * rl * o.qu[k]) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * o.qu[k]));
-            o.su[k] = (hu[k] - (1.0 - dcol * (tu[k] - tmelt)) * rl * o.qu[k]) / ((1.0 + cpvir * o.qu[k]) * cp);
+            const double quk = A.q[mx];
+            A.qu[k] = quk;
+            const double tuk = (A.hu[k] - grav * A.zf[k] - (1.0 + dcol * tmelt) * rl * quk) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * quk));
+            A.tu[k] = tuk;
+            A.su[k] = (A.hu[k] - (1.0 - dcol * (tuk - tmelt)) * rl * quk) / ((1.0 + cpvir * quk) * cp);
         }
         if ((k > o.jt && k < jb) && eps0 > 0.0) {
-            o.su[k] = o.mu[k + 1] / o.mu[k] * o.su[k + 1] + dz[k] / o.mu[k] * (o.eu[k] - o.du[k]) * s[k];
-            o.qu[k] = o.mu[k + 1] / o.mu[k] * o.qu[k + 1] + dz[k] / o.mu[k] * (o.eu[k] * q[k] - o.du[k] * o.qst[k]);
+            const double muk = A.mu[k], mukp1 = A.mu[k + 1], dzk = A.dz[k], euk = A.eu[k], duk = A.du[k];
+            const double suk = mukp1 / muk * A.su[k + 1] + dzk / muk * (euk - duk) * A.s[k];
+            const double quk = mukp1 / muk * A.qu[k + 1] + dzk / muk * (euk * A.q[k] - duk * A.qst[k]);
+            A.su[k] = suk; A.qu[k] = quk;
             // 0.85 is a default-REAL literal in the reference (:3680): single precision, then promoted
-            tu[k] = o.su[k] - grav / ((1.0 + (double)0.85f * o.qu[k]) * cp) * zf[k];
-            qsat_hPa(P, tu[k], (p[k] + p[k - 1]) / 2.0, estu, qstu);
-            if (o.qu[k] >= qstu) {
+            const double tuk = suk - grav / ((1.0 + (double)0.85f * quk) * cp) * A.zf[k];
+            A.tu[k] = tuk;
+            double estu, qstu;
+            qsat_hPa(P, tuk, (A.p[k] + A.p[k - 1]) / 2.0, estu, qstu);
+            if (quk >= qstu) {
                 o.jlcl = k;
                 break;                                                                       // :3690
             }
         }
     }
-    for (int k = msg + 2; k <= pver; ++k) {                                                  // :3693-3707
+    SYNC();
+    PAR(k, msg + 2, pver) {                                                                  // :3693-3707
         if ((k > o.jt && k <= o.jlcl) && eps0 > 0.0) {
-            o.qu[k] = qsthat[k] + gamhat[k] * (hu[k] - hsthat[k]) / ((1.0 - dcol * (tu[k] - tmelt)) * rl * (1.0 + gamhat[k]));
-            o.su[k] = shat[k] + (hu[k] - hsthat[k]) / ((1.0 + cpvir * o.qu[k]) * cp * (1.0 + gamhat[k]));
-            tu[k] = o.su[k] - grav / ((1.0 + cpvir * o.qu[k]) * cp) * zf[k];
+            const double gh = A.gamhat[k], dh = A.hu[k] - A.hsthat[k];
+            const double quk = A.qsthat[k] + gh * dh / ((1.0 - dcol * (A.tu[k] - tmelt)) * rl * (1.0 + gh));
+            const double suk = A.shat[k] + dh / ((1.0 + cpvir * quk) * cp * (1.0 + gh));
+            A.qu[k] = quk; A.su[k] = suk;
+            A.tu[k] = suk - grav / ((1.0 + cpvir * quk) * cp) * A.zf[k];
         }
     }
-    for (int k = pver; k >= msg + 2; --k) {                                                  // :3716-3739
+    SYNC();
+    PAR(k, msg + 2, pver) {                                                                  // :3716-3739
         if (k >= o.jt && k < jb && eps0 > 0.0) {
-            o.cu[k] = ((o.mu[k] * o.su[k] - o.mu[k + 1] * o.su[k + 1]) / dz[k] - (o.eu[k] - o.du[k]) * s[k]) / (rl / cp)
-                      * ((1.0 + cpvir * o.qu[k]) / (1.0 - dcol * (tu[k] - tmelt)));
-            if (k == o.jt) o.cu[k] = 0.0;
-            o.cu[k] = fmax(0.0, o.cu[k]);
+            double cuk = ((A.mu[k] * A.su[k] - A.mu[k + 1] * A.su[k + 1]) / A.dz[k] - (A.eu[k] - A.du[k]) * A.s[k]) / (rl / cp)
+                         * ((1.0 + cpvir * A.qu[k]) / (1.0 - dcol * (A.tu[k] - tmelt)));
+            if (k == o.jt) cuk = 0.0;
+            A.cu[k] = fmax(0.0, cuk);
         }
     }
+    SYNC();
     for (int k = pver; k >= msg + 2; --k) {                                                  // :3846-3870
-        o.rprd[k] = 0.0;
-        if (k >= o.jt && k < jb && eps0 > 0.0 && o.mu[k] >= 0.0) {
-            if (o.mu[k] > 0.0) {
-                ql1 = 1.0 / o.mu[k] * (o.mu[k + 1] * o.ql[k + 1] - dz[k] * o.du[k] * o.ql[k + 1] + dz[k] * o.cu[k]);
-                o.ql[k] = ql1 / (1.0 + dz[k] * c0mask);
+        double rp = 0.0;
+        const double muk = A.mu[k];
+        if (k >= o.jt && k < jb && eps0 > 0.0 && muk >= 0.0) {
+            const double dzk = A.dz[k], duk = A.du[k], cuk = A.cu[k], qlkp1 = A.ql[k + 1];
+            double qlk;
+            if (muk > 0.0) {
+                const double ql1 = 1.0 / muk * (A.mu[k + 1] * qlkp1 - dzk * duk * qlkp1 + dzk * cuk);
+                qlk = ql1 / (1.0 + dzk * c0mask);
             } else {
-                o.ql[k] = 0.0;
+                qlk = 0.0;
             }
-            totpcp = totpcp + dz[k] * (o.cu[k] - o.du[k] * o.ql[k + 1]);
-            o.rprd[k] = c0mask * o.mu[k] * o.ql[k];
-            o.qcde[k] = o.ql[k];
+            A.ql[k] = qlk;
+            totpcp = totpcp + dzk * (cuk - duk * qlkp1);
+            rp = c0mask * muk * qlk;
+            A.qcde[k] = qlk;
         }
+        A.rprd[k] = rp;
     }
 
     // downdraft :3880-3975
@@ -708,83 +819,107 @@ __device__ void cldprp_d(const ZmDev &P, int pver, int msg, const double *q, con
     o.jt = min(o.jt, jb - 1);
     o.jd = max(o.j0, o.jt + 1);
     o.jd = min(o.jd, jb);
-    hd[o.jd] = hmn[o.jd - 1];
-    if (o.jd < jb && eps0 > 0.0) {
+    const int jd = o.jd, jt = o.jt;
+    A.hd[jd] = A.hmn[jd - 1];
+    if (jd < jb && eps0 > 0.0) {
         epsm = eps0;
-        o.md[o.jd] = -alfa * epsm / eps0;
+        A.md[jd] = -alfa * epsm / eps0;
     }
-    for (int k = msg + 1; k <= pver; ++k) {                                                  // :3896-3904
-        if ((k > o.jd && k <= jb) && eps0 > 0.0) {
-            zdef = zf[o.jd] - zf[k];
-            o.md[k] = -alfa / (2.0 * eps0) * (exp(2.0 * epsm * zdef) - 1.0) / zdef;
+    SYNC();
+    const double zf_jd = A.zf[jd];
+    PAR(k, msg + 1, pver) {                                                                  // :3896-3904
+        if ((k > jd && k <= jb) && eps0 > 0.0) {
+            const double zdef = zf_jd - A.zf[k];
+            A.md[k] = -alfa / (2.0 * eps0) * (exp(2.0 * epsm * zdef) - 1.0) / zdef;
         }
     }
-    for (int k = msg + 1; k <= pver; ++k) {                                                  // :3906-3913
-        if ((k >= o.jt && k <= jb) && eps0 > 0.0 && o.jd < jb) {
-            ratmjb = fmin(fabs(o.mu[jb] / o.md[jb]), 1.0);
-            o.md[k] = o.md[k] * ratmjb;
+    SYNC();
+    if (eps0 > 0.0 && jd < jb) {                                                             // :3906-3913
+        const double ratmjb = fmin(fabs(A.mu[jb] / A.md[jb]), 1.0);   // md(jb) as it is before its own scaling
+        SYNC();
+        PAR(k, msg + 1, pver) {
+            if (k >= jt && k <= jb) A.md[k] = A.md[k] * ratmjb;
         }
     }
+    SYNC();
     for (int k = msg + 1; k <= pver; ++k) {                                                  // :3916-3924
-        if ((k >= o.jt && k <= pver) && eps0 > 0.0) {
-            o.ed[k - 1] = (o.md[k - 1] - o.md[k]) / dz[k - 1];
-            mdt = fmin(o.md[k], -small);
-            hd[k] = (o.md[k - 1] * hd[k - 1] - dz[k - 1] * o.ed[k - 1] * hmn[k - 1]) / mdt;
+        if ((k >= jt && k <= pver) && eps0 > 0.0) {
+            const double edkm1 = (A.md[k - 1] - A.md[k]) / A.dz[k - 1];
+            A.ed[k - 1] = edkm1;
+            mdt = fmin(A.md[k], -small);
+            A.hd[k] = (A.md[k - 1] * A.hd[k - 1] - A.dz[k - 1] * edkm1 * A.hmn[k - 1]) / mdt;
         }
     }
-    for (int k = msg + 2; k <= pver; ++k) {                                                  // :3928-3941
-        if ((k >= o.jd && k <= jb) && eps0 > 0.0 && o.jd < jb) {
-            qds[k] = qsthat[k] + gamhat[k] * (hd[k] - hsthat[k]) / (rl * (1.0 + gamhat[k]));
-            td[k] = (hd[k] - grav * zf[k] - (1.0 + dcol * tmelt) * rl * qds[k]) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * qds[k]));
-            qds[k] = qsthat[k] + gamhat[k] * (hd[k] - hsthat[k]) / ((1.0 - dcol * (td[k] - tmelt)) * rl * (1.0 + gamhat[k]));
+    SYNC();
+    PAR(k, msg + 2, pver) {                                                                  // :3928-3941
+        if ((k >= jd && k <= jb) && eps0 > 0.0 && jd < jb) {
+            const double gh = A.gamhat[k], dh = A.hd[k] - A.hsthat[k];
+            double qds = A.qsthat[k] + gh * dh / (rl * (1.0 + gh));
+            const double tdk = (A.hd[k] - grav * A.zf[k] - (1.0 + dcol * tmelt) * rl * qds) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * qds));
+            A.td[k] = tdk;
+            qds = A.qsthat[k] + gh * dh / ((1.0 - dcol * (tdk - tmelt)) * rl * (1.0 + gh));
+            A.qds[k] = qds;
         }
     }
+    SYNC();
     {                                                                                        // :3943-3951
-        const int k = o.jd;
-        o.qd[k] = qds[k];
-        o.sd[k] = (hd[k] - (1.0 - dcol * (td[k] - tmelt)) * rl * o.qd[k]) / ((1.0 + cpvir * o.qd[k]) * cp);
-        td[k] = o.sd[k] - grav / ((1.0 + cpvir * o.qd[k]) * cp) * zf[k];
+        const int k = jd;
+        const double qdk = A.qds[k];
+        A.qd[k] = qdk;
+        const double sdk = (A.hd[k] - (1.0 - dcol * (A.td[k] - tmelt)) * rl * qdk) / ((1.0 + cpvir * qdk) * cp);
+        A.sd[k] = sdk;
+        A.td[k] = sdk - grav / ((1.0 + cpvir * qdk) * cp) * A.zf[k];
     }
     for (int k = msg + 2; k <= pver; ++k) {                                                  // :3953-3971
-        if (k >= o.jd && k < jb && eps0 > 0.0) {
-            o.qd[k + 1] = qds[k + 1];
-            o.evp[k] = -o.ed[k] * q[k] + (o.md[k] * o.qd[k] - o.md[k + 1] * o.qd[k + 1]) / dz[k];
-            o.evp[k] = fmax(o.evp[k], 0.0);
-            mdt = fmin(o.md[k + 1], -small);
-            o.sd[k + 1] = (((1.0 - dcol * (td[k] - tmelt)) * rl / ((1.0 + cpvir * o.qd[k]) * cp) * o.evp[k] - o.ed[k] * s[k]) * dz[k]
-                           + o.md[k] * o.sd[k]) / mdt;
-            totevp = totevp - dz[k] * o.ed[k] * q[k];
+        if (k >= jd && k < jb && eps0 > 0.0) {
+            const double qdkp1 = A.qds[k + 1];
+            A.qd[k + 1] = qdkp1;
+            const double edk = A.ed[k], qk = A.q[k], dzk = A.dz[k], mdk = A.md[k], mdkp1 = A.md[k + 1], qdk = A.qd[k];
+            double evpk = -edk * qk + (mdk * qdk - mdkp1 * qdkp1) / dzk;
+            evpk = fmax(evpk, 0.0);
+            A.evp[k] = evpk;
+            mdt = fmin(mdkp1, -small);
+            A.sd[k + 1] = (((1.0 - dcol * (A.td[k] - tmelt)) * rl / ((1.0 + cpvir * qdk) * cp) * evpk - edk * A.s[k]) * dzk + mdk * A.sd[k]) / mdt;
+            totevp = totevp - dzk * edk * qk;
         }
     }
-    totevp = totevp + o.md[o.jd] * o.qd[o.jd] - o.md[jb] * o.qd[jb];                         // :3974
+    totevp = totevp + A.md[jd] * A.qd[jd] - A.md[jb] * A.qd[jb];                             // :3974
     totpcp = fmax(totpcp, 0.0);
     totevp = fmax(totevp, 0.0);
-    for (int k = msg + 2; k <= pver; ++k) {                                                  // :3993-4009
+    SYNC();
+    PAR(k, msg + 2, pver) {                                                                  // :3993-4009
+        double evpk;
         if (totevp > 0.0 && totpcp > 0.0) {
-            o.md[k] = o.md[k] * fmin(1.0, totpcp / (totevp + totpcp));
-            o.ed[k] = o.ed[k] * fmin(1.0, totpcp / (totevp + totpcp));
-            o.evp[k] = o.evp[k] * fmin(1.0, totpcp / (totevp + totpcp));
+            A.md[k] = A.md[k] * fmin(1.0, totpcp / (totevp + totpcp));
+            A.ed[k] = A.ed[k] * fmin(1.0, totpcp / (totevp + totpcp));
+            evpk = A.evp[k] * fmin(1.0, totpcp / (totevp + totpcp));
         } else {
-            o.md[k] = 0.0; o.ed[k] = 0.0; o.evp[k] = 0.0;
+            A.md[k] = 0.0; A.ed[k] = 0.0; evpk = 0.0;
         }
-        o.cmeg[k] = o.cu[k] - o.evp[k];
-        o.rprd[k] = o.rprd[k] - o.evp[k];
+        A.evp[k] = evpk;
+        A.cmeg[k] = A.cu[k] - evpk;
+        A.rprd[k] = A.rprd[k] - evpk;
     }
-    o.pflx[1] = 0.0;                                                                         // :4012-4017
-    for (int k = 2; k <= pver + 1; ++k) o.pflx[k] = o.pflx[k - 1] + o.rprd[k - 1] * dz[k - 1];
-    for (int k = msg + 1; k <= pver; ++k) o.mc[k] = o.mu[k] + o.md[k];
+    SYNC();
+    {                                                                                        // :4012-4017 prefix sum
+        double pf = 0.0;
+        A.pflx[1] = 0.0;
+        for (int k = 2; k <= pver + 1; ++k) {
+            pf = pf + A.rprd[k - 1] * A.dz[k - 1];
+            A.pflx[k] = pf;
+        }
+    }
+    PAR(k, msg + 1, pver) A.mc[k] = A.mu[k] + A.md[k];                                       // :4019-4023
+    SYNC();
 }
 
-// closure :4028-4260
-template <int ML>
-__device__ double closure_d(const ZmDev &P, int pver, int msg, const double *q, const double *t, const double *p,
-                            const double *s, const double *tp, const CldOut<ML> &cl, const double *qhat,
-                            const double *shat, const double *dp, const double *qstp, const double *zf, double dsubcld,
-                            double cape, double tl, int lcl, int lel, int jt, int mx)
+// closure :4028-4260: the per-level integrand one level per lane, the sum in the reference's order
+__device__ double closure_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, double *s_dboy, double dsubcld, double cape,
+                            double tl, int lcl, int lel, int jt, int mx, int lane)
 {
     const double rd = P.rgas, cp = P.cp, rl = P.rl, eps1 = P.eps1, grav = P.grav;
-    const double *mu = cl.mu, *md = cl.md, *su = cl.su, *sd = cl.sd, *qu = cl.qu, *qd = cl.qd, *mc = cl.mc, *du = cl.du,
-                 *ql = cl.ql;
+    const double *q = A.q, *t = A.t, *p = A.p, *s = A.s, *tp = A.tp, *qstp = A.qstp, *qhat = A.qhat, *shat = A.shat, *dp = A.dp;
+    const double *mu = A.mu, *md = A.md, *su = A.su, *sd = A.sd, *qu = A.qu, *qd = A.qd, *mc = A.mc, *du = A.du, *ql = A.ql;
     double mb = 0.0;
     const double eb = p[mx] * q[mx] / (eps1 + q[mx]);
     const double dtbdt = (1.0 / dsubcld) * (mu[mx] * (shat[mx] - su[mx]) + md[mx] * (shat[mx] - sd[mx]));
@@ -794,8 +929,7 @@ __device__ double closure_d(const ZmDev &P, int pver, int msg, const double *q, 
     const double dtldt = -2840.0 * (3.5 / t[mx] * dtbdt - debdt / eb) / (lg * lg);
     const double beta = 0.0;
 
-    double dadt = 0.0;
-    for (int k = lel; k <= mx - 1; ++k) {
+    PAR(k, lel, mx - 1) {
         double dtmdt = 0.0, dqmdt = 0.0, dboydt;
         if (k == jt && k <= pver - 1) {                                                      // :4154-4169
             dqmdt = (1.0 / dp[k]) * (mu[k + 1] * (qu[k + 1] - qhat[k + 1] + ql[k + 1]) + md[k + 1] * (qd[k + 1] - qhat[k + 1]));
@@ -824,71 +958,43 @@ __device__ double closure_d(const ZmDev &P, int pver, int msg, const double *q, 
             dboydt = (dtbdt / t[mx] + 0.608 / (1.0 + 0.608 * q[mx]) * dqbdt - dtmdt / t[k]
                       - 0.608 / (1.0 + 0.608 * q[k]) * dqmdt) * grav * thetavp / thetavm;
         }
-        dadt = dadt + dboydt * (zf[k] - zf[k + 1]);                                          // :4247-4253
+        s_dboy[k] = dboydt;
     }
+    SYNC();
+    double dadt = 0.0;                                                                       // :4244-4253
+    for (int k = lel; k <= mx - 1; ++k) dadt = dadt + s_dboy[k] * (A.zf[k] - A.zf[k + 1]);
     const double dltaa = -1.0 * (cape - P.capelmt);
     if (dadt != 0.0) mb = fmax(dltaa / P.tau / dadt, 0.0);
     return mb;
 }
 
-__device__ void interface_values_d(int pver, int msg, const double *sg, const double *qg, double *shat, double *qhat)
-{   // :1007-1027
-    for (int k = msg + 2; k <= pver; ++k) {
-        double sdifr = 0.0, qdifr = 0.0;
-        if (sg[k] > 0.0 || sg[k - 1] > 0.0) sdifr = fabs((sg[k] - sg[k - 1]) / fmax(sg[k - 1], sg[k]));
-        if (qg[k] > 0.0 || qg[k - 1] > 0.0) qdifr = fabs((qg[k] - qg[k - 1]) / fmax(qg[k - 1], qg[k]));
-        if (sdifr > 1.E-6) shat[k] = log(sg[k - 1] / sg[k]) * sg[k - 1] * sg[k] / (sg[k - 1] - sg[k]);
-        else shat[k] = 0.5 * (sg[k] + sg[k - 1]);
-        if (qdifr > 1.E-6) qhat[k] = log(qg[k - 1] / qg[k]) * qg[k - 1] * qg[k] / (qg[k - 1] - qg[k]);
-        else qhat[k] = 0.5 * (qg[k] + qg[k - 1]);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------
-// Kernel 2: plume ensemble, second ascent, closure, tendencies -- first-pass triggered columns only
+// Kernel 2a: first cloud-ensemble pass -> the test parcel's entrainment rate for the second ascent (:1032-1078)
 // ------------------------------------------------------------------------------------------------------
-template <int ML>
-__global__ __launch_bounds__(WAVE) void zm_plume_kernel(ZmDev P, int ncol, int pver, double delt, colphys_zm_convr_io io,
-                                                       ZmWorkspace ws)
+__global__ __launch_bounds__(WAVE) void zm_plume1_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io, ZmWorkspace ws)
 {
-    extern __shared__ double smem[];            // [(pver+2)][WAVE]
+    extern __shared__ double smem[];
     const int lane = threadIdx.x;
-    const int gid = blockIdx.x * WAVE + lane;
-    const int count = *ws.count;
-    if (gid >= count) return;
-    const int col = ws.list[gid];
     const int msg = P.limcnv - 1;
-    const size_t L = (size_t)pver, LP = (size_t)pver + 1;
-
+    const int LD = pver + 2;
+    PlumeLds A;
+    A.carve(smem, LD);
+    const int count = *ws.count;
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {      // persistent waves over the triggered list
+    const int col = ws.list[b];
     const ColIn c = make_colin(P, io, col, pver);
-    double q[ML], t[ML], p[ML], z[ML], s[ML], zf[ML], shat[ML], qhat[ML], dp[ML], tp[ML], qstp[ML];
-    CldOut<ML> cl;
-
-    zf[pver + 1] = c.Zf(pver + 1);
-    for (int k = 1; k <= pver; ++k) {                                                        // :825-860, 926-940
-        q[k] = c.Q(k); t[k] = c.T(k); p[k] = c.Pm(k); z[k] = c.Z(k); zf[k] = c.Zf(k);
-        s[k] = t[k] + (P.grav / ((1.0 + P.zvir * q[k]) * P.cpres)) * z[k];
-        shat[k] = s[k]; qhat[k] = q[k];
-        dp[k] = 0.01 * c.dpp[k];
-    }
-    const double pblt = pbl_top_index(c);
-
-    int maxg = ws.mx1[col], lelg = ws.lel1[col];
-    double dsubcld = 0.0;
-    for (int k = msg + 1; k <= pver; ++k)                                                    // :995-1001
-        if (k >= maxg) dsubcld = dsubcld + dp[k];
-    interface_values_d(pver, msg, s, q, shat, qhat);
-
-    cldprp_d<ML>(P, pver, msg, q, t, p, z, s, zf, shat, qhat, maxg, lelg, c.landfrac, cl);   // :1032
-
+    plume_load(P, c, A, lane);
+    PlumeIdx ix;
+    cldprp_w(P, pver, msg, A, ws.mx1[col], ws.lel1[col], c.landfrac, lane, ix);              // :1032
     double dmpdz = -1.0;                                                                     // :1046-1078
     {
         double hk = 0.0, dmmx = 0.0, dmsm = 0.0;
         const double orgc = 1.0;
         for (int k = pver; k >= msg + 1; --k) {
-            if (cl.eu[k] > 0) {
-                dmmx = -fmax(-dmmx, cl.eu[k]);
-                dmsm = dmsm - cl.eu[k];
+            const double e = A.eu[k];
+            if (e > 0) {
+                dmmx = -fmax(-dmmx, e);
+                dmsm = dmsm - e;
                 hk = hk + 1.0;
             }
         }
@@ -897,111 +1003,158 @@ __global__ __launch_bounds__(WAVE) void zm_plume_kernel(ZmDev P, int ncol, int p
             dmpdz = dmsm * orgc + dmmx * (1.0 - orgc);
         }
     }
+    if (lane == 0) ws.dmpdz2[col] = dmpdz;
+    SYNC();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Kernel 2b: second dilute ascent of the listed columns with that rate, re-trigger (:1080-1107)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void zm_ascent2_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io, ZmWorkspace ws)
+{
+    extern __shared__ double smem[];            // [(pver+2)][WAVE]
+    const int lane = threadIdx.x;
+    const int gid = blockIdx.x * WAVE + lane;
+    if (gid >= *ws.count) return;
+    const int col = ws.list[gid];
+    const size_t L = (size_t)pver;
+    const ColIn c = make_colin(P, io, col, pver);
+    const double pblt = pbl_top_index(c);
     BuoyRes r;
-    buoyan_dilute_d<true>(P, c, pblt, dmpdz, ws.cin1[col], smem + lane, tp, qstp, r);        // :1080
+    buoyan_dilute_d<true>(P, c, pblt, ws.dmpdz2[col], ws.cin1[col], smem + lane, ws.tp2 + col * L - 1, ws.qstp2 + col * L - 1, r);
     io.cape[col] = r.cape;
     io.status[col] |= r.status;
-    if (!(r.cape > P.capelmt && r.cin < r.cape * P.cin_threshd)) return;                     // :1099-1107
+    ws.cape2[col] = r.cape; ws.tl2[col] = r.tl; ws.lcl2[col] = r.lcl; ws.lel2[col] = r.lel; ws.mx2[col] = r.mx;
+    ws.retrig[col] = (r.cape > P.capelmt && r.cin < r.cape * P.cin_threshd) ? 1 : 0;        // :1099-1107
+}
 
-    maxg = r.mx; lelg = r.lel;                                                               // :1156-1195
-    dsubcld = 0.0;
+// ------------------------------------------------------------------------------------------------------
+// Kernel 2c: second ensemble pass, closure, tendencies, precipitation integrals of the re-triggered columns
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void zm_plume2_kernel(ZmDev P, int ncol, int pver, double delt, colphys_zm_convr_io io,
+                                                        ZmWorkspace ws)
+{
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    const int msg = P.limcnv - 1;
+    const int LD = pver + 2;
+    const size_t L = (size_t)pver, LP = (size_t)pver + 1;
+    PlumeLds A;
+    A.carve(smem, LD);
+    double *s_w1 = smem + (size_t)PLUME_NARR * LD, *s_w2 = s_w1 + LD;       // dboydt / dqdt, dl
+    const int count = *ws.count;
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {      // persistent waves over the triggered list
+    const int col = ws.list[b];
+    if (!ws.retrig[col]) continue;
+    const ColIn c = make_colin(P, io, col, pver);
+    plume_load(P, c, A, lane);
+    PAR(k, 1, pver) { A.tp[k] = ws.tp2[col * L + k - 1]; A.qstp[k] = ws.qstp2[col * L + k - 1]; }
+
+    const int maxg = ws.mx2[col], lelg = ws.lel2[col], lcl = ws.lcl2[col];                   // :1156-1174
+    const double cape = ws.cape2[col], tl = ws.tl2[col], dmpdz = ws.dmpdz2[col];
+    double dsubcld = 0.0;
     for (int k = msg + 1; k <= pver; ++k)
-        if (k >= maxg) dsubcld = dsubcld + dp[k];
-    // shat/qhat depend only on s, q: unchanged (:1175-1195 recompute the same values)
+        if (k >= maxg) dsubcld = dsubcld + A.dp[k];
 
-    cldprp_d<ML>(P, pver, msg, q, t, p, z, s, zf, shat, qhat, maxg, lelg, c.landfrac, cl);   // :1216
+    PlumeIdx ix;
+    cldprp_w(P, pver, msg, A, maxg, lelg, c.landfrac, lane, ix);                             // :1216
+    const int jt = ix.jt, mx = maxg;
 
-    for (int k = msg + 1; k <= pver; ++k) {                                                  // :1252-1262
-        const double dzk = (zf[k] - zf[k + 1]);
-        cl.du[k] = cl.du[k] * dzk / dp[k];   cl.eu[k] = cl.eu[k] * dzk / dp[k];   cl.ed[k] = cl.ed[k] * dzk / dp[k];
-        cl.cu[k] = cl.cu[k] * dzk / dp[k];   cl.cmeg[k] = cl.cmeg[k] * dzk / dp[k]; cl.rprd[k] = cl.rprd[k] * dzk / dp[k];
-        cl.evp[k] = cl.evp[k] * dzk / dp[k];
+    PAR(k, msg + 1, pver) {                                                                  // :1252-1262
+        const double dzk = (A.zf[k] - A.zf[k + 1]), dpk = A.dp[k];
+        A.du[k] = A.du[k] * dzk / dpk;   A.eu[k] = A.eu[k] * dzk / dpk;   A.ed[k] = A.ed[k] * dzk / dpk;
+        A.cu[k] = A.cu[k] * dzk / dpk;   A.cmeg[k] = A.cmeg[k] * dzk / dpk; A.rprd[k] = A.rprd[k] * dzk / dpk;
+        A.evp[k] = A.evp[k] * dzk / dpk;
     }
-
-    double mb = closure_d<ML>(P, pver, msg, q, t, p, s, tp, cl, qhat, shat, dp, qstp, zf, dsubcld, r.cape, r.tl, r.lcl,
-                              lelg, cl.jt, maxg);                                            // :1273
+    SYNC();
+    double mb = closure_w(P, pver, msg, A, s_w1, dsubcld, cape, tl, lcl, lelg, jt, mx, lane);                // :1273
     double mumax = 0;                                                                        // :1285-1300
-    for (int k = msg + 2; k <= pver; ++k) mumax = fmax(mumax, cl.mu[k] / dp[k]);
+    for (int k = msg + 2; k <= pver; ++k) mumax = fmax(mumax, A.mu[k] / A.dp[k]);
     if (mumax > 0.0) mb = fmin(mb, 0.5 / (delt * mumax));
     else mb = 0.0;
     if (P.no_deep_pbl) {                                                                     // :1304-1308
-        if (c.zm[cl.jt] < c.pblh) mb = 0;
+        if (c.zm[jt] < c.pblh) mb = 0;
     }
-    for (int k = msg + 1; k <= pver; ++k) {                                                  // :1319-1331
-        cl.mu[k] = cl.mu[k] * mb; cl.md[k] = cl.md[k] * mb; cl.mc[k] = cl.mc[k] * mb; cl.du[k] = cl.du[k] * mb;
-        cl.eu[k] = cl.eu[k] * mb; cl.ed[k] = cl.ed[k] * mb; cl.cmeg[k] = cl.cmeg[k] * mb; cl.rprd[k] = cl.rprd[k] * mb;
-        cl.cu[k] = cl.cu[k] * mb; cl.evp[k] = cl.evp[k] * mb;
-        cl.pflx[k + 1] = cl.pflx[k + 1] * mb * 100.0 / P.grav;
+    SYNC();
+    PAR(k, msg + 1, pver) {                                                                  // :1319-1331
+        A.mu[k] = A.mu[k] * mb; A.md[k] = A.md[k] * mb; A.mc[k] = A.mc[k] * mb; A.du[k] = A.du[k] * mb;
+        A.eu[k] = A.eu[k] * mb; A.ed[k] = A.ed[k] * mb; A.cmeg[k] = A.cmeg[k] * mb; A.rprd[k] = A.rprd[k] * mb;
+        A.cu[k] = A.cu[k] * mb; A.evp[k] = A.evp[k] * mb;
+        A.pflx[k + 1] = A.pflx[k + 1] * mb * 100.0 / P.grav;
     }
+    SYNC();
 
-    // q1q2_pjr :4262-4421 fused with the scatter :1495-1511 and the integrals :1629-1649
+    // q1q2_pjr :4262-4421: the flux-form tendencies are element-wise; levels below the launch level copy it
+    double *dqdt = s_w1, *dlg = s_w2;
+    const double rl = P.rl, cp = P.cp;
     double *o_qtnd = io.qtnd + col * L - 1, *o_heat = io.heat + col * L - 1, *o_cme = io.cme + col * L - 1,
            *o_zdu = io.zdu + col * L - 1, *o_rprd = io.rprd + col * L - 1, *o_dlf = io.dlf + col * L - 1,
            *o_ql = io.ql + col * L - 1, *o_eurt = io.eurt + col * L - 1, *o_mcon = io.mcon + col * LP - 1,
            *o_pflx = io.pflx + col * LP - 1;
-    const double rl = P.rl, cp = P.cp;
-    const int jt = cl.jt, mx = maxg;
-    double dsdt_km1 = 0.0, dqdt_km1 = 0.0;
-    double *dqdt = tp, *dlg = qstp;            // reuse private profiles
-    for (int k = msg + 1; k <= pver; ++k) {
+    double dsdt_mx = 0.0, dqdt_mx = 0.0;
+    if (mx >= msg + 1 && mx <= pver) {                                                       // :4402-4412
+        dsdt_mx = (1.0 / dsubcld) * (-A.mu[mx] * (A.su[mx] - A.shat[mx]) - A.md[mx] * (A.sd[mx] - A.shat[mx]));
+        dqdt_mx = (1.0 / dsubcld) * (-A.mu[mx] * (A.qu[mx] - A.qhat[mx]) - A.md[mx] * (A.qd[mx] - A.qhat[mx]));
+    }
+    PAR(k, msg + 1, pver) {
         double dsdt = 0.0, dq = 0.0, dl = 0.0;
         if (k >= jt && k <= pver - 1) {                                                      // :4364-4399
-            const double emc = -cl.cu[k] + cl.evp[k];
-            dsdt = -rl / cp * emc + (cl.mu[k + 1] * (cl.su[k + 1] - shat[k + 1]) - cl.mu[k] * (cl.su[k] - shat[k])
-                                     + cl.md[k + 1] * (cl.sd[k + 1] - shat[k + 1]) - cl.md[k] * (cl.sd[k] - shat[k])) / dp[k];
-            dq = emc + (cl.mu[k + 1] * (cl.qu[k + 1] - qhat[k + 1]) - cl.mu[k] * (cl.qu[k] - qhat[k])
-                        + cl.md[k + 1] * (cl.qd[k + 1] - qhat[k + 1]) - cl.md[k] * (cl.qd[k] - qhat[k])) / dp[k];
-            dl = cl.du[k] * cl.qcde[k + 1];
+            const double emc = -A.cu[k] + A.evp[k];
+            dsdt = -rl / cp * emc + (A.mu[k + 1] * (A.su[k + 1] - A.shat[k + 1]) - A.mu[k] * (A.su[k] - A.shat[k])
+                                     + A.md[k + 1] * (A.sd[k + 1] - A.shat[k + 1]) - A.md[k] * (A.sd[k] - A.shat[k])) / A.dp[k];
+            dq = emc + (A.mu[k + 1] * (A.qu[k + 1] - A.qhat[k + 1]) - A.mu[k] * (A.qu[k] - A.qhat[k])
+                        + A.md[k + 1] * (A.qd[k + 1] - A.qhat[k + 1]) - A.md[k] * (A.qd[k] - A.qhat[k])) / A.dp[k];
+            dl = A.du[k] * A.qcde[k + 1];
         }
-        if (k == mx) {                                                                       // :4402-4418
-            dsdt = (1.0 / dsubcld) * (-cl.mu[k] * (cl.su[k] - shat[k]) - cl.md[k] * (cl.sd[k] - shat[k]));
-            dq = (1.0 / dsubcld) * (-cl.mu[k] * (cl.qu[k] - qhat[k]) - cl.md[k] * (cl.qd[k] - qhat[k]));
-        } else if (k > mx) {
-            dsdt = dsdt_km1;
-            dq = dqdt_km1;
-        }
-        dsdt_km1 = dsdt; dqdt_km1 = dq;
+        if (k >= mx) { dsdt = dsdt_mx; dq = dqdt_mx; }                                       // :4404-4416
         dqdt[k] = dq; dlg[k] = dl;
         o_qtnd[k] = dq;                                                                      // :1495-1511
-        o_cme[k] = cl.cmeg[k];
-        o_rprd[k] = cl.rprd[k];
-        o_zdu[k] = cl.du[k];
-        o_mcon[k] = cl.mc[k];
+        o_cme[k] = A.cmeg[k];
+        o_rprd[k] = A.rprd[k];
+        o_zdu[k] = A.du[k];
+        o_mcon[k] = A.mc[k];
         o_heat[k] = dsdt * P.cpres;
         o_dlf[k] = dl;
-        o_pflx[k] = cl.pflx[k];
-        o_ql[k] = cl.ql[k];
+        o_pflx[k] = A.pflx[k];
+        o_ql[k] = A.ql[k];
         o_eurt[k] = -dmpdz;                                                                  // :1233-1237
     }
-    io.jctop[col] = jt;                                                                      // :1616-1620
-    io.jcbot[col] = maxg;
-    o_pflx[pver + 1] = cl.pflx[pver + 1];
-
+    // full-layout plume profiles; zm_gather_kernel compacts them per chunk
+    PAR(k, 1, pver) {
+        const size_t g = col * L + k - 1;
+        ws.mu_f[g] = A.mu[k]; ws.md_f[g] = A.md[k]; ws.du_f[g] = A.du[k]; ws.eu_f[g] = A.eu[k]; ws.ed_f[g] = A.ed[k];
+        ws.dp_f[g] = A.dp[k];
+    }
+    SYNC();
     double prec = 0.0, rliq = 0.0;
     for (int k = pver; k >= msg + 1; --k) {                                                  // :1629-1633 (dif == 0)
-        const double qnew = q[k] + 2.0 * delt * dqdt[k];
-        prec = prec - c.dpp[k] * (qnew - q[k]) - c.dpp[k] * (dlg[k] + 0.0) * 2.0 * delt;
+        const double qk = A.q[k], dppk = c.dpp[k];
+        const double qnew = qk + 2.0 * delt * dqdt[k];
+        prec = prec - dppk * (qnew - qk) - dppk * (dlg[k] + 0.0) * 2.0 * delt;
     }
     prec = P.rgrav * fmax(prec, 0.0) / (2.0 * delt) / 1000.0;                                // :1637
     for (int k = 1; k <= pver; ++k) {                                                        // :1642-1649
         const double dlfk = (k >= msg + 1) ? dlg[k] : 0.0;
         rliq = rliq + (dlfk + 0.0) * c.dpp[k] / P.gravit;
     }
-    io.prec[col] = prec;
-    io.rliq[col] = rliq / 1000.0;
-    io.rice[col] = 0.0 / 1000.0;
-
-    // full-layout plume profiles; zm_gather_kernel compacts them per chunk
-    double *w_mu = ws.mu_f + col * L - 1, *w_md = ws.md_f + col * L - 1, *w_du = ws.du_f + col * L - 1,
-           *w_eu = ws.eu_f + col * L - 1, *w_ed = ws.ed_f + col * L - 1, *w_dp = ws.dp_f + col * L - 1;
-    for (int k = 1; k <= pver; ++k) {
-        w_mu[k] = cl.mu[k]; w_md[k] = cl.md[k]; w_du[k] = cl.du[k]; w_eu[k] = cl.eu[k]; w_ed[k] = cl.ed[k]; w_dp[k] = dp[k];
+    if (lane == 0) {
+        io.jctop[col] = jt;                                                                  // :1616-1620
+        io.jcbot[col] = maxg;
+        o_pflx[pver + 1] = A.pflx[pver + 1];
+        io.prec[col] = prec;
+        io.rliq[col] = rliq / 1000.0;
+        io.rice[col] = 0.0 / 1000.0;
+        ws.dsub_f[col] = dsubcld;
+        ws.jt_f[col] = jt;
+        ws.maxg_f[col] = maxg;
+        ws.deep[col] = 1;
     }
-    ws.dsub_f[col] = dsubcld;
-    ws.jt_f[col] = jt;
-    ws.maxg_f[col] = maxg;
-    ws.deep[col] = 1;
+    SYNC();
+    }
 }
+#undef PAR
+#undef SYNC
 
 // ------------------------------------------------------------------------------------------------------
 // Kernel 3: per-chunk ascending compaction into the reference's gathered layout
@@ -1051,12 +1204,11 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     if (ev) hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(zm_trigger_kernel, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, io, ws);
     if (ev) { hipEventRecord(ev[1], st); hipEventRecord(ev[2], st); }
-    if (pver <= 32)
-        hipLaunchKernelGGL(zm_plume_kernel<36>, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, delt, io, ws);
-    else if (pver <= 72)
-        hipLaunchKernelGGL(zm_plume_kernel<76>, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, delt, io, ws);
-    else
-        hipLaunchKernelGGL(zm_plume_kernel<COLPHYS_MAX_PVER + 4>, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, delt, io, ws);
+    const size_t lds_w = (size_t)(PLUME_NARR + 2) * (pver + 2) * sizeof(double);
+    const int nper = ncol < 256 * 12 ? ncol : 256 * 12;       // persistent: ~12 waves per CU fit in LDS at L32
+    hipLaunchKernelGGL(zm_plume1_kernel, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, io, ws);
+    hipLaunchKernelGGL(zm_ascent2_kernel, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, io, ws);
+    hipLaunchKernelGGL(zm_plume2_kernel, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, delt, io, ws);
     hipLaunchKernelGGL(zm_gather_kernel, dim3(nchunks), dim3(WAVE), 0, st, ncol, pver, pcols, io, ws);
     if (ev) hipEventRecord(ev[3], st);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
