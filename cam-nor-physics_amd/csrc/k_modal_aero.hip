@@ -45,11 +45,17 @@ constexpr int TBLP = AERO_TBLP;             // 420 doubles per table in the pack
 
 struct Wght { double wt1, wt2; int ix1, ix2; };
 
+// Wave-uniform table constants are read through the constant address space: such loads stay scalar (SGPR results,
+// scalar cache) even though the kernel also issues LDS-DMA copies, which the compiler otherwise treats as stores
+// that could clobber any global load and turns every uniform load into a vector load waiting on vmcnt with the DMA.
+typedef const __attribute__((address_space(4))) double *cptr_t;
+__device__ __forceinline__ cptr_t as_const(const double *p) { return (cptr_t)(const void *)p; }
+
 // calcwghts of table_interp: first grid point above x (the reference's loop with exit), extrapolating below the
 // grid and clamping above it.  g: the grid through a wave-uniform global pointer (scalar loads -> SGPR operands);
 // s_g: the same grid in LDS for the two data-dependent reads.
 template <int N>
-__device__ __forceinline__ Wght calcwghts(const double *g, const double *s_g, double x)
+__device__ __forceinline__ Wght calcwghts(cptr_t g, const double *s_g, double x)
 {
     int ii = N + 1;
 #pragma unroll
@@ -173,11 +179,11 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
             vol[l] = 0.0;
             if (l < nspec) vol[l] = io.specmmr[((size_t)m * A.nspec_max + l) * F + cc];
         }
-        size_parameters(A, A.sigmag[m], dgn, radsurf, logradsurf, cheb);
+        size_parameters(A, as_const(A.sigmag)[m], dgn, radsurf, logradsurf, cheb);
 #pragma unroll
         for (int l = 0; l < NSMAX; ++l) {                               // :764-766
             if (l < nspec) {
-                vol[l] = vol[l] / A.specdens[m * A.nspec_max + l];
+                vol[l] = vol[l] / as_const(A.specdens)[m * A.nspec_max + l];
                 dryvol = dryvol + vol[l];
             }
         }
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
                 slice_issue<SLICE>(slices + ((size_t)mn * nb + b0 + jn) * SLICE, s_slice0 + (cur ^ 1) * SLICE);
             }
             // volume-mixed complex refractive index :767, 846-850 / :1360, 1375-1378
-            const double *ri = (SW ? A.specrefindex_sw : A.specrefindex_lw) + ((size_t)m * A.nspec_max * nb + ib) * 2;
+            cptr_t ri = as_const((SW ? A.specrefindex_sw : A.specrefindex_lw) + ((size_t)m * A.nspec_max * nb + ib) * 2);
             double cre = 0.0, cim = 0.0;
 #pragma unroll
             for (int l = 0; l < NSMAX; ++l) {
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
                     cim = cim + vol[l] * ri[(size_t)l * nb * 2 + 1];
                 }
             }
-            const double *crefw = (SW ? A.crefwsw : A.crefwlw) + ib * 2;
+            cptr_t crefw = as_const((SW ? A.crefwsw : A.crefwlw) + ib * 2);
             cre = cre + watervol * crefw[0];
             cim = cim + watervol * crefw[1];
             double refr, refi;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
                 const bool dv = wetvol > 1.e-40;
                 refr = dv ? qr : cre; refi = dv ? qi : cim;
             }
-            const double *g_grid = slices + gsl * SLICE + NTAB * TBLP;  // uniform -> scalar loads
+            cptr_t g_grid = as_const(slices + gsl * SLICE + NTAB * TBLP);   // uniform -> scalar loads
             const Wght wr = calcwghts<NR>(g_grid, s_refr, refr);        // :857-858 / :1383-1384
             const Wght wi = calcwghts<NI>(g_grid + NR, s_refi, refi);
 
