@@ -166,7 +166,7 @@ def main():
 
     # The optics kernels share no data with the ZM chain, so they go on a second HIP stream and fill the SIMDs
     # the latency-bound ZM kernels leave idle (760 waves, then ~80, on 1 024 SIMDs); --serial disables it.
-    side = torch.cuda.Stream() if (with_aero and not args.serial) else None
+    side = torch.cuda.Stream(priority=0) if (with_aero and not args.serial) else None
 
     def aero():
         eng.modal_aero_sw(S["pdeldry"], A["specmmr"], A["dgnumwet"], A["qaerwat"], out=sw_out)
@@ -217,7 +217,7 @@ def main():
         substep()                                   # allocates the engine's workspaces before capture
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        cap = torch.cuda.Stream()
+        cap = torch.cuda.Stream(priority=-1)        # the ZM chain is the critical path: high-priority queue
         cap.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap):
             with torch.cuda.graph(graph, stream=cap):

@@ -11,6 +11,15 @@
 
 #define WAVE 64
 
+// The ZM chain (trigger -> plume -> evaporation -> momentum -> update -> geopotential) is a sequence of
+// latency-bound launches with few waves; the aerosol optics on the second stream are throughput work that shares
+// the SIMDs with it.  Chain kernels raise their waves' issue priority so that the optics fill the chain's stalls
+// instead of time-slicing with it (s_setprio: wave priority at the SIMD's instruction arbiter).
+#ifndef COLPHYS_CHAIN_PRIO
+#define COLPHYS_CHAIN_PRIO 3
+#endif
+#define CHAIN_PRIO() __builtin_amdgcn_s_setprio(COLPHYS_CHAIN_PRIO)
+
 // Parameters as the kernels see them: colphys_zm_params plus the values zm_convi derives
 // (zm_conv.F90:145-155).  Passed BY VALUE as a kernel argument (wave-uniform => SGPRs / scalar loads).
 struct ZmDev {

@@ -8,8 +8,8 @@
 //   work item  = one cell; a block is 4 waves = 256 consecutive cells of the [ncol][pver] layout
 //                (coalesced reads of pdeldry / dgnumwet / qaerwat / specmmr);
 //   grid.y     = band group: the SW bands are split into groups so that the group's running sums
-//                tau, tau*w, tau*w*g, tau*w*g^2 for 256 cells fit in LDS next to the tables and two blocks
-//                share a CU (the per-(cell, mode) size/volume prologue is recomputed per group: ~10 % work);
+//                tau, tau*w, tau*w*g, tau*w*g^2 for 256 cells fit in LDS next to the tables and three blocks
+//                share a CU (the per-(cell, mode) size/volume prologue is recomputed per group);
 //   LDS        = (a) the (mode, band) slice of the coefficient tables -- ext/abs/asm(5,7,10) + the two
 //                refractive-index grids -- because each cell gathers 4 corners x 5 coefficients x 3 tables
 //                per (mode, band) at data-dependent indices; coefficients padded 5 -> 6 so a corner is
@@ -26,12 +26,15 @@
 #include "colphys_common.h"
 
 #ifndef AERO_MIN_WAVES
-#define AERO_MIN_WAVES 2
+#define AERO_MIN_WAVES 3                   // 3 waves / SIMD: the kernel needs ~136 VGPRs
 #endif
 #ifndef AERO_LDS_CAP_KB
-#define AERO_LDS_CAP_KB 78
+#define AERO_LDS_CAP_KB 53                 // three blocks per CU (A/B on MI355X: 53 KB x 3 beats 78 KB x 2)
 #endif
-#ifdef AERO_CONTRACT
+// Unlike the ZM kernels (Brent iterations with discrete stopping tests) the optics are straight polynomial /
+// bilinear arithmetic, so FMA contraction is allowed here: -8 % time; measured against the reference goldens the
+// worst relative error is 3.5e-15 with and 3.2e-15 without (scripts/parity_report.py).  -DAERO_NO_CONTRACT undoes it.
+#ifndef AERO_NO_CONTRACT
 #pragma clang fp contract(fast)
 #endif
 
@@ -296,7 +299,7 @@ static int launch_aero(bool sw, const AeroDev &A, int ncol, int pver, const colp
     const int nb = sw ? A.nswbands : A.nlwbands;
     const int ntab = sw ? 3 : 1, nout = sw ? 4 : 1;
     const size_t slice = (size_t)aero_slice_doubles(ntab);
-    // band groups: largest group whose accumulators + 2 slices stay within ~76 KB (two blocks per CU)
+    // band groups: largest group whose accumulators + 2 slices stay within AERO_LDS_CAP_KB (three blocks per CU)
     int ngroups = 1;
     for (;; ++ngroups) {
         const int bpg = (nb + ngroups - 1) / ngroups;

@@ -19,6 +19,7 @@ constexpr int NT = WAVE;
 __global__ __launch_bounds__(NT) void momtran_wave_kernel(ZmDev P, int ncol, int pver, int pcols, double dt,
                                                          colphys_momtran_io io)
 {
+    CHAIN_PRIO();
     extern __shared__ double smem[];
     const int row = blockIdx.x;                               // gathered row of the flat layout
     const int ic = row / pcols, c0 = ic * pcols, slot = row - c0;
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(NT) void momtran_wave_kernel(ZmDev P, int ncol, int
 // initialisation of the full-layout outputs (:2429-2443), element-wise
 __global__ void momtran_init_kernel(size_t n2, size_t n1, colphys_momtran_io io)
 {
+    CHAIN_PRIO();
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
         const double w = io.winds[i];

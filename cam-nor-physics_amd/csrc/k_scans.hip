@@ -62,6 +62,7 @@ __global__ __launch_bounds__(NT) void geopotential_kernel(int ncol, int pver, in
                                                          double gravit, const double *__restrict__ zvir,
                                                          double *__restrict__ zi, double *__restrict__ zm)
 {
+    CHAIN_PRIO();
     extern __shared__ double smem[];
     const int col0 = blockIdx.x * GT;
     const int nc = min(GT, ncol - col0);
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(NT) void geopotential_kernel(int ncol, int pver, in
 __global__ __launch_bounds__(NT) void zm_conv_evap_kernel(ZmDev P, const double *__restrict__ estbl, int ncol, int pver,
                                                          double deltat, colphys_zm_conv_evap_io io)
 {
+    CHAIN_PRIO();
     extern __shared__ double smem[];
     __shared__ double s_estbl[COLPHYS_PLENEST + 1];
     const int col0 = blockIdx.x * TILE;
@@ -352,6 +354,7 @@ __global__ void physics_update_kernel(size_t n, double dt, double cpair, double 
                                       const double *__restrict__ u_tend, double *u_out, const double *__restrict__ v_in,
                                       const double *__restrict__ v_tend, double *v_out)
 {
+    CHAIN_PRIO();
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         if (t_out) t_out[i] = t_in[i] + s_tend[i] * dt / cpair;            // physics_types.F90:427

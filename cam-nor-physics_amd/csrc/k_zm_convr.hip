@@ -436,6 +436,7 @@ __device__ __forceinline__ void block_fill(double *p, size_t n, double v)
 __global__ __launch_bounds__(WAVE) void zm_trigger_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io,
                                                          ZmWorkspace ws)
 {
+    CHAIN_PRIO();
     extern __shared__ double smem[];            // [(pver+2)][WAVE]
     const int col0 = blockIdx.x * WAVE;
     const int nb = min(WAVE, ncol - col0);
@@ -973,6 +974,7 @@ __device__ double closure_w(const ZmDev &P, int pver, int msg, const PlumeLds &A
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WAVE) void zm_plume1_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io, ZmWorkspace ws)
 {
+    CHAIN_PRIO();
     extern __shared__ double smem[];
     const int lane = threadIdx.x;
     const int msg = P.limcnv - 1;
@@ -1013,6 +1015,7 @@ __global__ __launch_bounds__(WAVE) void zm_plume1_kernel(ZmDev P, int ncol, int 
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WAVE) void zm_ascent2_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io, ZmWorkspace ws)
 {
+    CHAIN_PRIO();
     extern __shared__ double smem[];            // [(pver+2)][WAVE]
     const int lane = threadIdx.x;
     const int gid = blockIdx.x * WAVE + lane;
@@ -1035,6 +1038,7 @@ __global__ __launch_bounds__(WAVE) void zm_ascent2_kernel(ZmDev P, int ncol, int
 __global__ __launch_bounds__(WAVE) void zm_plume2_kernel(ZmDev P, int ncol, int pver, double delt, colphys_zm_convr_io io,
                                                         ZmWorkspace ws)
 {
+    CHAIN_PRIO();
     extern __shared__ double smem[];
     const int lane = threadIdx.x;
     const int msg = P.limcnv - 1;
@@ -1161,6 +1165,7 @@ __global__ __launch_bounds__(WAVE) void zm_plume2_kernel(ZmDev P, int ncol, int 
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WAVE) void zm_gather_kernel(int ncol, int pver, int pcols, colphys_zm_convr_io io, ZmWorkspace ws)
 {
+    CHAIN_PRIO();
     __shared__ int s_src[1024];
     __shared__ int s_n;
     const int c0 = blockIdx.x * pcols;
