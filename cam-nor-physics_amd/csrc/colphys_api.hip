@@ -386,6 +386,16 @@ int colphys_physics_update_dev(int ncol, int pver, double dt, double cpair, doub
     return rc ? fail(rc, "physics_update launch failed") : COLPHYS_OK;
 }
 
+int colphys_math_probe_dev(int kind, int64_t n, const double *x, double *y, void *stream)
+{
+    int rc;
+    if ((rc = check_ready())) return rc;
+    if (kind < COLPHYS_PROBE_LOG || kind > COLPHYS_PROBE_SVP) return fail(COLPHYS_ERR_ARG, "unknown probe kind");
+    if (n < 0 || (n > 0 && (!x || !y))) return fail(COLPHYS_ERR_ARG, "bad probe arguments");
+    rc = launch_math_probe(kind, n, x, y, (hipStream_t)stream);
+    return rc ? fail(rc, "math probe launch failed") : COLPHYS_OK;
+}
+
 // ---- aerosol tables -------------------------------------------------------------------------------------
 int colphys_aero_tables_set(const colphys_aero_tables *tb)
 {

@@ -55,14 +55,76 @@ constexpr int aero_slice_doubles(int ntab)
     return ((ntab * AERO_TBLP + COLPHYS_PREFR + COLPHYS_PREFI) * 8 + 1023) / 1024 * 128;
 }
 
+// ---- logarithms -----------------------------------------------------------------------------------------
+// The dilute-parcel ascent spends ~45 % of its instructions in log / log10 (three per entropy evaluation inside
+// Brent's iteration).  ROCm's OCML log is ~90 VALU instructions; this is the classical argument-reduction form
+//     x = 2^k m,  m in [sqrt(1/2), sqrt(2)),  f = m - 1,  s = f/(2+f),  log m = f - (f^2/2 - s (f^2/2 + R(s^2)))
+// with the degree-7 minimax R of that scheme (Remez coefficients as published with Sun's fdlibm): < 1 ulp, the same
+// accuracy class as OCML and as the host libm the reference links, in ~45 instructions.  Neither is bit-identical
+// to the reference's libm; parity is 1e-10 relative either way ("transcendentals").
+// Zero, negative, infinite and NaN arguments take OCML's path, so exceptional values propagate as before.
+__device__ __forceinline__ void cp_log_core(double x, double &dk, double &lm)
+{
+    const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
+                 L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+                 L7 = 1.479819860511658591e-01;
+    int k = __builtin_amdgcn_frexp_exp(x);            // x = mant * 2^k, mant in [0.5, 1); denormals included
+    double m = __builtin_amdgcn_frexp_mant(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, L6, L4), L2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, L7, L5), L3), L1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    dk = (double)k;
+    lm = f - (hfsq - s * (hfsq + R));
+}
+__device__ __forceinline__ double cp_log(double x)
+{
+    if (!(x > 0.0 && x < __builtin_inf())) return log(x);
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
+                 L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+                 L7 = 1.479819860511658591e-01;
+    int k = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, L6, L4), L2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, L7, L5), L3), L1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+__device__ __forceinline__ double cp_log10(double x)
+{
+    if (!(x > 0.0 && x < __builtin_inf())) return log10(x);
+    const double ivln10_hi = 4.34294481903251816668e-01, ivln10_lo = 1.09831965021676507e-17;
+    const double log10_2hi = 0.3010299955494702, log10_2lo = 1.1451100898021838e-10;   // hi: 32 significant bits
+    double dk, lm;
+    cp_log_core(x, dk, lm);
+    return dk * log10_2hi + (dk * log10_2lo + __builtin_fma(lm, ivln10_lo, lm * ivln10_hi));
+}
+
 // ---- saturation vapour pressure: Goff-Gratch over water / ice (spec: oracle/stubs/l0_arithmetic.F90) ----
 __device__ inline double svp_water_gg(double t)
 {
     const double tboil = 373.16;
-    return exp10(-7.90298 * (tboil / t - 1.0) + 5.02808 * log10(tboil / t)
+    return exp10(-7.90298 * (tboil / t - 1.0) + 5.02808 * cp_log10(tboil / t)
                  - 1.3816e-7 * (exp10(11.344 * (1.0 - t / tboil)) - 1.0)
                  + 8.1328e-3 * (exp10(-3.49149 * (tboil / t - 1.0)) - 1.0)
-                 + log10(1013.246)) * 100.0;
+                 + 3.0057148979490314) * 100.0;        // log10(1013.246), correctly rounded
 }
 
 // ---- launchers implemented in the k_*.hip files ------------------------------------------------------
@@ -97,4 +159,5 @@ int launch_physics_update(int ncol, int pver, double dt, double cpair, double qm
                           const double *s_tend, double *t_out, const double *q_in, const double *q_tend, double *q_out,
                           const double *u_in, const double *u_tend, double *u_out, const double *v_in,
                           const double *v_tend, double *v_out, hipStream_t st);
+int launch_math_probe(int kind, int64_t n, const double *x, double *y, hipStream_t st);
 int launch_convtran(int ncol, int pver, int pcols, int ncnst, const colphys_convtran_io &io, hipStream_t st);

@@ -429,3 +429,23 @@ int launch_convtran(int ncol, int pver, int pcols, int ncnst, const colphys_conv
     }
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
+
+// ---- diagnostic probe of the scalar device functions (colphys_math_probe_dev) ----------------------------
+namespace {
+__global__ void math_probe_kernel(int kind, int64_t n, const double *__restrict__ x, double *__restrict__ y)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double v = x[i];
+        y[i] = kind == COLPHYS_PROBE_LOG ? cp_log(v) : (kind == COLPHYS_PROBE_LOG10 ? cp_log10(v) : svp_water_gg(v));
+    }
+}
+}  // namespace
+
+int launch_math_probe(int kind, int64_t n, const double *x, double *y, hipStream_t st)
+{
+    if (n <= 0) return COLPHYS_OK;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(math_probe_kernel, dim3(blocks), dim3(256), 0, st, kind, n, x, y);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}

@@ -25,8 +25,9 @@
 // and the CAPE/CIN sums, :4773-4810); it is kept in LDS as [level][lane].
 //
 // Arithmetic: fp64, no FMA contraction (-ffp-contract=off), operation order of the reference.
-// Transcendentals are ROCm OCML (exp10/log10/log/exp/pow): not bit-identical to the host libm the
-// reference Fortran links, which is why parity is stated as 1e-10 relative, not bitwise.
+// Transcendentals are ROCm OCML (exp10/exp/pow) and the < 1 ulp logarithms of colphys_common.h: not
+// bit-identical to the host libm the reference Fortran links, which is why parity is stated as 1e-10
+// relative, not bitwise.
 #include "colphys_common.h"
 
 namespace {
@@ -52,8 +53,8 @@ __device__ __forceinline__ double entropy_d(const ZmDev &P, double TK, double p,
     qsat_hPa(P, TK, p, est, qst);
     double qv = fmin(qtot, qst);
     double e = qv * p / (P.eps1 + qv);
-    return (P.cpres + qtot * P.cpliq) * log(TK / P.tfreez) - P.rgas * log((p - e) / pref) + L * qv / TK
-           - qv * P.rh2o * log(qv / qst);
+    return (P.cpres + qtot * P.cpliq) * cp_log(TK / P.tfreez) - P.rgas * cp_log((p - e) / pref) + L * qv / TK
+           - qv * P.rh2o * cp_log(qv / qst);
 }
 
 __device__ __forceinline__ double enthalpy_d(const ZmDev &P, double TK, double p, double qtot, double z)
@@ -73,8 +74,11 @@ __device__ __forceinline__ double enthalpy_d(const ZmDev &P, double TK, double p
 //  (2) entropy: while the parcel is unsaturated at the trial temperature (qv = qt) the term
 //      log((p - e)/pref) does not depend on T: it is computed once per inversion and reused;
 //  (3) entropy: when saturated, qv = qst and log(qv/qst) = log(1) = 0 exactly: the logarithm is skipped.
+#ifndef BRENT_INLINE
+#define BRENT_INLINE __forceinline__
+#endif
 template <int KIND>
-__device__ __noinline__ int invert_brent(const ZmDev &P, double s, double p, double z, double qt, double &T, double &qst,
+__device__ BRENT_INLINE int invert_brent(const ZmDev &P, double s, double p, double z, double qt, double &T, double &qst,
                                          double Tfg)
 {
     const int LOOPMAX = 100;
@@ -88,7 +92,7 @@ __device__ __noinline__ int invert_brent(const ZmDev &P, double s, double p, dou
     double lg_unsat = 0.0;
     if (KIND == 0) {
         const double e_unsat = qt * p / (P.eps1 + qt);
-        lg_unsat = log((p - e_unsat) / 1000.0);
+        lg_unsat = cp_log((p - e_unsat) / 1000.0);
     }
 
     auto feval = [&](double TK, double &qs_out) -> double {
@@ -101,13 +105,13 @@ __device__ __noinline__ int invert_brent(const ZmDev &P, double s, double p, dou
         double lgp, lgq;
         if (qv == qt) {                        // unsaturated (or exactly saturated): e depends on qt only
             lgp = lg_unsat;
-            lgq = log(qv / qs);
+            lgq = cp_log(qv / qs);
         } else {                               // saturated: qv = qs
             const double e = qv * p / (P.eps1 + qv);
-            lgp = log((p - e) / 1000.0);
+            lgp = cp_log((p - e) / 1000.0);
             lgq = 0.0;                         // log(qs/qs)
         }
-        return ((P.cpres + qt * P.cpliq) * log(TK / P.tfreez) - P.rgas * lgp + L * qv / TK - qv * P.rh2o * lgq) - s;   // :5297
+        return ((P.cpres + qt * P.cpliq) * cp_log(TK / P.tfreez) - P.rgas * lgp + L * qv / TK - qv * P.rh2o * lgq) - s;   // :5297
     };
 
     a = Tfg - 10;
@@ -325,7 +329,7 @@ __device__ void buoyan_dilute_d(const ZmDev &P, const ColIn &c, double pblt, dou
 #pragma unroll 1
         for (int ii = 0; ii < 2; ++ii) {
             xsh2o = fmax(0.0, qtmix - qsmix - lwmax);
-            ds_xsh2o = ds_xsh2o_kp1 - P.cpliq * log(tmix / P.tfreez) * fmax(0.0, (xsh2o - xsh2o_kp1));
+            ds_xsh2o = ds_xsh2o_kp1 - P.cpliq * cp_log(tmix / P.tfreez) * fmax(0.0, (xsh2o - xsh2o_kp1));
             if (tmix <= P.tfreez + tscool && ds_freeze_kp1 == 0.0)
                 ds_freeze = (P.latice / tmix) * fmax(0.0, qtmix - qsmix - xsh2o);
             if (tmix <= P.tfreez + tscool && ds_freeze_kp1 != 0.0)
@@ -384,7 +388,7 @@ __device__ void buoyan_dilute_d(const ZmDev &P, const ColIn &c, double pblt, dou
             double ct = 0.0, ci = 0.0;
             for (int k = max(msg + 1, lelten[n] + 1); k <= klaunch; ++k) {
                 const double bk = s_tpv[k * WAVE];
-                const double lg = log(c.Pf(k + 1) / c.Pf(k));
+                const double lg = cp_log(c.Pf(k + 1) / c.Pf(k));
                 ct = ct + P.rgas * bk * lg;
                 ci = ci - P.rgas * fmin(bk, 0.0) * lg;
             }

@@ -60,7 +60,7 @@ EXPORTED_SYMBOLS = [
     "colphys_convtran_dev", "colphys_convtran_chunks", "colphys_physics_update_dev", "colphys_aero_tables_set",
     "colphys_modal_aero_sw_dev", "colphys_modal_aero_lw_dev",
     "colphys_modal_aero_sw_chunks", "colphys_modal_aero_lw_chunks",
-    "colphys_profile_enable", "colphys_profile_reset", "colphys_profile_get",
+    "colphys_profile_enable", "colphys_profile_reset", "colphys_profile_get", "colphys_math_probe_dev",
 ]
 
 
@@ -218,6 +218,16 @@ class ColumnPhysics:
             ptrs += [None, None, None] if tri is None else [_p(self._f64(x)) for x in tri]
         self._check(self.lib.colphys_physics_update_dev(C.c_int(n), C.c_int(pver), C.c_double(dt), C.c_double(cpair),
                                                         C.c_double(qmin), *ptrs, self._stream()))
+
+    # ---- diagnostic: the device log / log10 / svp_water the kernels use ------------------------------
+    PROBE = {"log": 0, "log10": 1, "svp_water": 2}
+
+    def math_probe(self, kind: str, x):
+        x = self._f64(x)
+        y = self.torch.empty_like(x)
+        self._check(self.lib.colphys_math_probe_dev(C.c_int(self.PROBE[kind]), C.c_int64(x.numel()), _p(x), _p(y),
+                                                    self._stream()))
+        return y
 
     # ---- modal aerosol optics (modal_aer_opt.F90:485,1216) ------------------------------------------
     def aero_tables_set(self, props: dict, physconst: dict):

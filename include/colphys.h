@@ -288,6 +288,18 @@ int colphys_profile_enable(int on);
 int colphys_profile_reset(void);
 int colphys_profile_get(int kernel, double *avg_ms, int64_t *launches);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Diagnostic: evaluates, element-wise on device arrays, the scalar device functions the kernels use where the
+ * reference calls its libm / its L0 saturation seam, so that their accuracy can be tested on its own:
+ *   COLPHYS_PROBE_LOG    y = log(x)      (entropy, zm_conv.F90:5297; CAPE integral :4790)
+ *   COLPHYS_PROBE_LOG10  y = log10(x)    (Goff-Gratch svp_water, oracle/stubs/l0_arithmetic.F90)
+ *   COLPHYS_PROBE_SVP    y = svp_water(x) [Pa], x = temperature [K]
+ * ------------------------------------------------------------------------------------------------- */
+#define COLPHYS_PROBE_LOG   0
+#define COLPHYS_PROBE_LOG10 1
+#define COLPHYS_PROBE_SVP   2
+int colphys_math_probe_dev(int kind, int64_t n, const double *x, double *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -298,3 +298,35 @@ def test_chunk_entry_points_match_device_entry_points():
             assert np.array_equal(hout[k][c, :, :lg].T, o[k][:lg]), k
         for k in ("jt", "maxg", "ideep"):
             assert np.array_equal(hout[k][c, 0, :lg], o[k][:lg]), k
+
+
+# ---------------------------------------------------------------------------------------------------
+# (d) the device logarithms that stand where the reference calls its libm
+# ---------------------------------------------------------------------------------------------------
+def test_device_logarithms_within_one_ulp_class():
+    """cp_log / cp_log10 (colphys_common.h) against numpy's libm over the ranges the kernels use and beyond:
+    <= 2 ulp everywhere (both sides are < 1 ulp implementations), exceptional arguments as libm."""
+    eng = engine(cases.default_params(32))
+    rng = np.random.default_rng(11)
+    x = np.concatenate([
+        rng.uniform(0.5, 2.0, 400000),                      # T/Tfreez, tboil/T, interface pressure ratios
+        10.0 ** rng.uniform(-12, 6, 400000),                # qv/qst, (p-e)/pref and far beyond
+        np.nextafter(1.0, 0) ** rng.integers(1, 1000, 1000), 1.0 + rng.uniform(-1e-8, 1e-8, 100000),
+        np.array([1.0, 2.0, 0.5, 4.9e-324, 2.2e-308, 1.7e308]),
+    ])
+    with np.errstate(all="ignore"):
+        for kind, ref in (("log", np.log), ("log10", np.log10)):
+            y = eng.math_probe(kind, eng.dev(x)).cpu().numpy()
+            r = ref(x)
+            ulp = np.abs(y - r) / np.spacing(np.abs(r))
+            ulp[r == 0.0] = np.abs(y[r == 0.0]) / np.spacing(1.0) * 0 + (y[r == 0.0] != 0.0)
+            assert ulp.max() <= 2.0, (kind, ulp.max(), x[np.argmax(ulp)])
+            bad = np.array([0.0, -1.0, np.inf, np.nan])
+            yb = eng.math_probe(kind, eng.dev(bad)).cpu().numpy()
+            assert yb[0] == -np.inf and np.isnan(yb[1]) and yb[2] == np.inf and np.isnan(yb[3])
+    t = rng.uniform(170.0, 330.0, 200000)
+    es = eng.math_probe("svp_water", eng.dev(t)).cpu().numpy()
+    tb = 373.16
+    es_ref = 10.0 ** (-7.90298 * (tb / t - 1.0) + 5.02808 * np.log10(tb / t) - 1.3816e-7 * (10.0 ** (11.344 * (1.0 - t / tb)) - 1.0)
+                      + 8.1328e-3 * (10.0 ** (-3.49149 * (tb / t - 1.0)) - 1.0) + np.log10(1013.246)) * 100.0
+    assert np.max(np.abs(es / es_ref - 1.0)) < 1e-14
