@@ -49,8 +49,9 @@ def substep_bytes(L):
             + BYTES["modal_aero_sw"](L) + BYTES["modal_aero_lw"](L))
 
 
-PMC_KERNEL = {"geopotential_t": "geopotential_kernel", "zm_trigger": "zm_trigger_kernel", "zm_plume": "zm_plume_kernel",
-              "zm_conv_evap": "zm_conv_evap_kernel", "momtran": "momtran_kernel", "modal_aero_sw": "modal_aero_kernel<true>",
+PMC_KERNEL = {"geopotential_t": "geopotential_kernel", "zm_trigger": "zm_trigger_kernel", "zm_plume1": "zm_plume1_kernel",
+              "zm_ascent2": "zm_ascent2_kernel", "zm_plume2": "zm_plume2_kernel",
+              "zm_conv_evap": "zm_conv_evap_kernel", "momtran": "momtran_wave_kernel", "modal_aero_sw": "modal_aero_kernel<true>",
               "modal_aero_lw": "modal_aero_kernel<false>"}
 
 

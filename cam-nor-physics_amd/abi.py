@@ -15,8 +15,8 @@ STATUS_DOPAER_RANGE = 2
 NCOEF, PREFR, PREFI = 5, 7, 10
 
 K_GEOPOTENTIAL, K_ZM_TRIGGER, K_ZM_PLUME, K_ZM_EVAP, K_MOMTRAN, K_AERO_SW, K_AERO_LW, K_UPDATE, K_CONVTRAN = range(9)
-KERNEL_NAMES = ["geopotential_t", "zm_trigger", "zm_plume", "zm_conv_evap", "momtran", "modal_aero_sw", "modal_aero_lw",
-                "physics_update", "convtran"]
+KERNEL_NAMES = ["geopotential_t", "zm_trigger", "zm_plume1", "zm_conv_evap", "momtran", "modal_aero_sw", "modal_aero_lw",
+                "physics_update", "convtran", "zm_ascent2", "zm_plume2"]
 
 
 class ZmParams(C.Structure):

@@ -312,12 +312,14 @@ int colphys_zm_convr_dev(int ncol, int pver, int pcols, double delt, const colph
         if (g_ws_arena.reserve(zm_ws_bytes(ncol, pver))) return fail(COLPHYS_ERR_HIP, "workspace allocation failed");
         ws = zm_ws_carve(g_ws_arena.p, ncol, pver);
     }
-    hipEvent_t ev[4];
+    hipEvent_t ev[8];
     if (g_prof) for (auto &e : ev) e = ev_get();
     rc = launch_zm_convr(g_P, ncol, pver, pcols, delt, *io, ws, st, g_prof ? ev : nullptr);
     if (g_prof) {
         g_pending.push_back({COLPHYS_K_ZM_TRIGGER, ev[0], ev[1]});
-        g_pending.push_back({COLPHYS_K_ZM_PLUME, ev[2], ev[3]});
+        g_pending.push_back({COLPHYS_K_ZM_PLUME1, ev[2], ev[3]});
+        g_pending.push_back({COLPHYS_K_ZM_ASCENT2, ev[4], ev[5]});
+        g_pending.push_back({COLPHYS_K_ZM_PLUME2, ev[6], ev[7]});
     }
     return rc ? fail(rc, "zm_convr launch failed") : COLPHYS_OK;
 }

@@ -148,7 +148,7 @@ struct ZmWorkspace {            // device scratch owned by the API layer (grow-o
     double *tp2, *qstp2;            // [ncol][pver]
 };
 int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io &io,
-                    const ZmWorkspace &ws, hipStream_t st, hipEvent_t *ev /* 4 events or null */);
+                    const ZmWorkspace &ws, hipStream_t st, hipEvent_t *ev /* 8 events or null */);
 
 int launch_zm_conv_evap(const ZmDev &P, const double *estbl_dev, int ncol, int pver, double deltat,
                         const colphys_zm_conv_evap_io &io, hipStream_t st);

@@ -1216,9 +1216,11 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     const size_t lds_w = (size_t)(PLUME_NARR + 2) * (pver + 2) * sizeof(double);
     const int nper = ncol < 256 * 12 ? ncol : 256 * 12;       // persistent: ~12 waves per CU fit in LDS at L32
     hipLaunchKernelGGL(zm_plume1_kernel, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, io, ws);
+    if (ev) { hipEventRecord(ev[3], st); hipEventRecord(ev[4], st); }
     hipLaunchKernelGGL(zm_ascent2_kernel, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, io, ws);
+    if (ev) { hipEventRecord(ev[5], st); hipEventRecord(ev[6], st); }
     hipLaunchKernelGGL(zm_plume2_kernel, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, delt, io, ws);
     hipLaunchKernelGGL(zm_gather_kernel, dim3(nchunks), dim3(WAVE), 0, st, ncol, pver, pcols, io, ws);
-    if (ev) hipEventRecord(ev[3], st);
+    if (ev) hipEventRecord(ev[7], st);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }

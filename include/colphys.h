@@ -276,14 +276,16 @@ int colphys_modal_aero_lw_chunks(int nchunks, int pcols, int pver, const int32_t
  * ------------------------------------------------------------------------------------------------- */
 #define COLPHYS_K_GEOPOTENTIAL 0
 #define COLPHYS_K_ZM_TRIGGER   1
-#define COLPHYS_K_ZM_PLUME     2
+#define COLPHYS_K_ZM_PLUME1    2   /* first cloud-ensemble pass of the triggered columns */
 #define COLPHYS_K_ZM_EVAP      3
 #define COLPHYS_K_MOMTRAN      4
 #define COLPHYS_K_AERO_SW      5
 #define COLPHYS_K_AERO_LW      6
 #define COLPHYS_K_UPDATE       7
 #define COLPHYS_K_CONVTRAN     8
-#define COLPHYS_K_COUNT        10
+#define COLPHYS_K_ZM_ASCENT2   9   /* second dilute ascent of the triggered columns */
+#define COLPHYS_K_ZM_PLUME2    10  /* second ensemble pass, closure, tendencies, gather */
+#define COLPHYS_K_COUNT        12
 int colphys_profile_enable(int on);
 int colphys_profile_reset(void);
 int colphys_profile_get(int kernel, double *avg_ms, int64_t *launches);
