@@ -185,6 +185,8 @@ int colphys_device_count(void)
     return n;
 }
 
+int colphys_is_initialized(void) { return g_init ? 1 : 0; }
+
 void colphys_zm_params_defaults(colphys_zm_params *p)
 {
     p->tiedke_lnd = 1.0; p->entrmn = 2e-4; p->alfadet = 0.1; p->plclmin = 6.e2; p->cin_threshd = 0.33;

@@ -51,7 +51,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = [
-    "colphys_abi_version", "colphys_last_error", "colphys_device_count", "colphys_zm_params_defaults",
+    "colphys_abi_version", "colphys_last_error", "colphys_device_count", "colphys_is_initialized", "colphys_zm_params_defaults",
     "colphys_init", "colphys_finalize",
     "colphys_geopotential_t_dev", "colphys_geopotential_t_chunks",
     "colphys_zm_convr_dev", "colphys_zm_convr_chunks",

@@ -41,9 +41,57 @@ module colphys_c_api
     type(c_ptr) :: dqdt
   end type colphys_convtran_io
 
+  type, bind(C) :: colphys_aero_tables
+    integer(c_int32_t) :: nmodes, nspec_max, nswbands, nlwbands
+    integer(c_int32_t) :: top_lev
+    integer(c_int32_t) :: idx_sw_diag, idx_uv_diag, idx_nir_diag
+    real(c_double) :: rhoh2o, rga, rair
+    real(c_double) :: xrmin, xrmax
+    type(c_ptr) :: nspec, spectype
+    type(c_ptr) :: sigmag, specdens, hygro
+    type(c_ptr) :: specrefindex_sw, specrefindex_lw
+    type(c_ptr) :: refrtabsw, refitabsw, refrtablw, refitablw
+    type(c_ptr) :: extpsw, abspsw, asmpsw, absplw
+    type(c_ptr) :: crefwsw, crefwlw
+  end type colphys_aero_tables
+
+  type, bind(C) :: colphys_modal_aero_io
+    type(c_ptr) :: pdeldry, pmid, t
+    type(c_ptr) :: specmmr
+    type(c_ptr) :: dgnumwet, qaerwat
+    type(c_ptr) :: troplevchem
+    type(c_ptr) :: tauxar, wa, ga, fa
+    type(c_ptr) :: status
+  end type colphys_modal_aero_io
+
   interface
     integer(c_int) function colphys_device_count() bind(C, name='colphys_device_count')
       import
+    end function
+    integer(c_int) function colphys_is_initialized() bind(C, name='colphys_is_initialized')
+      import
+    end function
+    subroutine colphys_zm_params_defaults(p) bind(C, name='colphys_zm_params_defaults')
+      import
+      type(colphys_zm_params), intent(out) :: p
+    end subroutine
+    integer(c_int) function colphys_aero_tables_set(tb) bind(C, name='colphys_aero_tables_set')
+      import
+      type(colphys_aero_tables), intent(in) :: tb
+    end function
+    integer(c_int) function colphys_modal_aero_sw_chunks(nchunks, pcols, pver, ncol, io) &
+         bind(C, name='colphys_modal_aero_sw_chunks')
+      import
+      integer(c_int), value :: nchunks, pcols, pver
+      integer(c_int32_t), intent(in) :: ncol(*)
+      type(colphys_modal_aero_io), intent(in) :: io
+    end function
+    integer(c_int) function colphys_modal_aero_lw_chunks(nchunks, pcols, pver, ncol, io) &
+         bind(C, name='colphys_modal_aero_lw_chunks')
+      import
+      integer(c_int), value :: nchunks, pcols, pver
+      integer(c_int32_t), intent(in) :: ncol(*)
+      type(colphys_modal_aero_io), intent(in) :: io
     end function
     integer(c_int) function colphys_init(device, p) bind(C, name='colphys_init')
       import

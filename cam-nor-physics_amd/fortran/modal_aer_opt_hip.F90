@@ -1,0 +1,362 @@
+! modal_aer_opt_hip -- ISO_C_BINDING shim: the reference's modal aerosol optics surface, bodies on the MI355X.
+!
+! Public procedures have the SAME names, argument lists, kinds and intents as the reference module
+! modal_aer_opt (NorESMhub/CAM-Nor-physics physics/modal_aer_opt.F90):
+!     modal_aer_opt_readnl :74      modal_aer_opt_init :113      modal_aero_sw :485-486      modal_aero_lw :1216
+! so the radiation-side caller (aer_rad_props: `call modal_aero_sw(list_idx, state, pbuf, nnite, idxnite, tauxar, wa,
+! ga, fa)`, `call modal_aero_lw(list_idx, state, pbuf, tauxar)`) compiles against it unchanged.
+!
+! What stays on the host, exactly where the reference has it: the accessors.  Mode / species properties come from
+! rad_constituents (rad_cnst_get_mode_props, rad_cnst_get_aer_props, rad_cnst_get_info), the mixing ratios from
+! rad_cnst_get_aer_mmr, wet size and aerosol water from the physics buffer (DGNUMWET, QAERWAT), the water refractive
+! index from the file named in the namelist through pio -- the same calls as modal_aer_opt.F90:153, 167-172,
+! 679-681, 717-724, 759-762, 1334-1355, 1485-1530.  The shim hands the tables to the engine once
+! (colphys_aero_tables_set) and per call marshals the chunk's fields to colphys_modal_aero_{sw,lw}_chunks.
+!
+! Not offloaded (DESIGN.md "out of scope"): the ~40 history diagnostics of modal_aero_sw (addfld/outfld :173-480,
+! :899-993, 1045-1208) and the diagnostic radiation lists (list_idx > 0, :683-699), which need the absent
+! modal_aero_calcsize / modal_aero_wateruptake; the shim aborts on list_idx > 0 instead of returning wrong numbers.
+!
+! Module name: `modal_aer_opt_hip` by default; with -DCOLPHYS_DROPIN_NAMES it is `modal_aer_opt`, a whole-module
+! replacement -- tests/ build it that way against the very wrapper source that drives the reference
+! (oracle/ref_wrap_aero.F90).
+#ifdef COLPHYS_DROPIN_NAMES
+#define AER_MODULE modal_aer_opt
+#else
+#define AER_MODULE modal_aer_opt_hip
+#endif
+
+module AER_MODULE
+  use iso_c_binding
+  use shr_kind_mod,      only: r8 => shr_kind_r8, shr_kind_cl
+  use ppgrid,            only: pcols, pver, pverp
+  use spmd_utils,        only: masterproc
+  use ref_pres,          only: top_lev => clim_modal_aero_top_lev
+  use physconst,         only: rhoh2o, rga, rair, cpair, epsilo, gravit, latice, latvap, tmelt, cpwv, cpliq, rh2o, &
+                               cpvir, zvir
+  use radconstants,      only: nswbands, nlwbands, idx_sw_diag, idx_uv_diag, idx_nir_diag
+  use rad_constituents,  only: n_diag, rad_cnst_get_call_list, rad_cnst_get_info, rad_cnst_get_aer_mmr, &
+                               rad_cnst_get_aer_props, rad_cnst_get_mode_props
+  use physics_types,     only: physics_state
+  use physics_buffer,    only: pbuf_get_index, physics_buffer_desc, pbuf_get_field
+  use pio,               only: file_desc_t, var_desc_t, pio_inq_dimlen, pio_inq_dimid, pio_inq_varid, &
+                               pio_get_var, pio_nowrite, pio_closefile
+  use cam_pio_utils,     only: cam_pio_openfile
+  use cam_logfile,       only: iulog
+  use cam_abortutils,    only: endrun
+  use colphys_c_api
+  implicit none
+  private
+  save
+
+  public :: modal_aer_opt_readnl, modal_aer_opt_init, modal_aero_sw, modal_aero_lw
+
+  integer, parameter :: ncoef = 5, prefr = 7, prefi = 10            ! modal_aer_opt.F90:56
+  character(len=*), parameter :: unset_str = 'UNSET'
+  character(shr_kind_cl) :: water_refindex_file = unset_str         ! namelist modal_aer_opt_nl (:51, :84)
+
+  integer :: dgnumwet_idx = -1, qaerwat_idx = -1                    ! physics buffer indices (:63-64)
+  integer :: nmodes_clim = 0, nspec_max = 0
+  integer(c_int32_t), allocatable, target :: nspec_m(:)
+
+contains
+
+  !---------------------------------------------------------------------------------------------------------
+  subroutine modal_aer_opt_readnl(nlfile)
+    ! modal_aer_opt.F90:74-109: the one namelist variable of group modal_aer_opt_nl, read on the master task
+    ! and broadcast
+    use namelist_utils, only: find_group_name
+    use units,          only: getunit, freeunit
+    use mpishorthand
+    character(len=*), intent(in) :: nlfile
+    integer :: u, ios
+    namelist /modal_aer_opt_nl/ water_refindex_file
+
+    if (masterproc) then
+      u = getunit()
+      open(u, file=trim(nlfile), status='old')
+      call find_group_name(u, 'modal_aer_opt_nl', status=ios)
+      if (ios == 0) then
+        read(u, modal_aer_opt_nl, iostat=ios)
+        if (ios /= 0) call endrun('modal_aer_opt_readnl:: ERROR reading namelist')
+      end if
+      close(u)
+      call freeunit(u)
+    end if
+#ifdef SPMD
+    call mpibcast(water_refindex_file, len(water_refindex_file), mpichar, 0, mpicom)
+#endif
+  end subroutine modal_aer_opt_readnl
+
+  !---------------------------------------------------------------------------------------------------------
+  subroutine modal_aer_opt_init()
+    ! modal_aer_opt.F90:113-480 without the history registration: size-range constants, consistency of the
+    ! coefficient-table dimensions, physics-buffer indices, water refractive index; then every table of the climate
+    ! list goes to the device once.
+    use ioFileMod, only: getfil
+    logical :: call_list(0:n_diag)
+    integer :: ilist, nmodes, m, l, ib, m_ncoef, m_prefr, m_prefi, errcode, nspec, rc
+    character(len=256) :: locfile
+    character(len=32)  :: spectype
+    real(r8) :: crefwsw(2, nswbands), crefwlw(2, nlwbands)
+    real(r8) :: specdens_1, hygro_1, sigma_1
+    complex(r8), pointer :: ri_sw(:), ri_lw(:)
+    real(r8), pointer :: p_refrsw(:,:), p_refisw(:,:), p_refrlw(:,:), p_refilw(:,:)
+    real(r8), pointer :: p_ext(:,:,:,:), p_abs(:,:,:,:), p_asm(:,:,:,:), p_abl(:,:,:,:)
+    integer(c_int32_t), allocatable, target :: spectype_c(:,:)
+    real(c_double), allocatable, target :: sigmag(:), specdens(:,:), hygro(:,:), sri_sw(:,:,:,:), sri_lw(:,:,:,:)
+    real(c_double), allocatable, target :: refrsw(:,:,:), refisw(:,:,:), refrlw(:,:,:), refilw(:,:,:)
+    real(c_double), allocatable, target :: ext(:,:,:,:,:), abss(:,:,:,:,:), asmp(:,:,:,:,:), abl(:,:,:,:,:)
+    real(c_double), target :: cw_sw(2, nswbands), cw_lw(2, nlwbands)
+    type(colphys_aero_tables) :: tb
+    type(colphys_zm_params) :: zp
+
+    call rad_cnst_get_call_list(call_list)                                          ! :148-163
+    do ilist = 0, n_diag
+      if (call_list(ilist)) then
+        call rad_cnst_get_info(ilist, nmodes=nmodes)
+        do m = 1, nmodes
+          call rad_cnst_get_mode_props(ilist, m, ncoef=m_ncoef, prefr=m_prefr, prefi=m_prefi)
+          if (m_ncoef /= ncoef .or. m_prefr /= prefr .or. m_prefi /= prefi) then
+            write(iulog,*) 'modal_aer_opt_init: ERROR - file and module values do not match:'
+            write(iulog,*) '   ncoef:', ncoef, m_ncoef, '   prefr:', prefr, m_prefr, '   prefi:', prefi, m_prefi
+            call endrun('modal_aer_opt_init: ERROR - file and module values do not match')
+          end if
+        end do
+      end if
+    end do
+
+    dgnumwet_idx = pbuf_get_index('DGNUMWET', errcode)                              ! :168-175
+    if (errcode < 0) call endrun('modal_aer_opt_init ERROR: cannot find physics buffer field DGNUMWET')
+    qaerwat_idx = pbuf_get_index('QAERWAT', errcode)
+    if (errcode < 0) call endrun('modal_aer_opt_init ERROR: cannot find physics buffer field QAERWAT')
+
+    call getfil(water_refindex_file, locfile)                                       ! :177-179
+    call read_water_refindex(locfile, cw_sw, cw_lw)
+    if (masterproc) write(iulog,*) 'modal_aer_opt_init: read water refractive index file:', trim(locfile)
+
+    ! ---- tables of the climate list (list_idx = 0), laid out as include/colphys.h describes ---------------
+    call rad_cnst_get_info(0, nmodes=nmodes_clim)
+    nmodes = nmodes_clim
+    if (allocated(nspec_m)) deallocate(nspec_m)
+    allocate(nspec_m(nmodes))
+    do m = 1, nmodes
+      call rad_cnst_get_info(0, m, nspec=nspec)
+      nspec_m(m) = nspec
+    end do
+    nspec_max = maxval(nspec_m)
+    allocate(spectype_c(nspec_max, nmodes), sigmag(nmodes), specdens(nspec_max, nmodes), hygro(nspec_max, nmodes), &
+             sri_sw(2, nswbands, nspec_max, nmodes), sri_lw(2, nlwbands, nspec_max, nmodes), &
+             refrsw(prefr, nswbands, nmodes), refisw(prefi, nswbands, nmodes), &
+             refrlw(prefr, nlwbands, nmodes), refilw(prefi, nlwbands, nmodes), &
+             ext(ncoef, prefr, prefi, nswbands, nmodes), abss(ncoef, prefr, prefi, nswbands, nmodes), &
+             asmp(ncoef, prefr, prefi, nswbands, nmodes), abl(ncoef, prefr, prefi, nlwbands, nmodes))
+    spectype_c = -1; specdens = 1._r8; hygro = 0._r8; sri_sw = 0._r8; sri_lw = 0._r8
+    do m = 1, nmodes
+      call rad_cnst_get_mode_props(0, m, sigmag=sigma_1, refrtabsw=p_refrsw, refitabsw=p_refisw, extpsw=p_ext, &
+                                   abspsw=p_abs, asmpsw=p_asm)                      ! :717-718
+      call rad_cnst_get_mode_props(0, m, refrtablw=p_refrlw, refitablw=p_refilw, absplw=p_abl)   ! :1334-1335
+      sigmag(m) = sigma_1
+      refrsw(:,:,m) = p_refrsw; refisw(:,:,m) = p_refisw; refrlw(:,:,m) = p_refrlw; refilw(:,:,m) = p_refilw
+      ext(:,:,:,:,m) = p_ext; abss(:,:,:,:,m) = p_abs; asmp(:,:,:,:,m) = p_asm; abl(:,:,:,:,m) = p_abl
+      do l = 1, nspec_m(m)
+        call rad_cnst_get_aer_props(0, m, l, density_aer=specdens_1, refindex_aer_sw=ri_sw, spectype=spectype, &
+                                    hygro_aer=hygro_1)                              ! :760-762
+        call rad_cnst_get_aer_props(0, m, l, refindex_aer_lw=ri_lw)                 ! :1354-1355
+        specdens(l, m) = specdens_1; hygro(l, m) = hygro_1
+        do ib = 1, nswbands
+          sri_sw(1, ib, l, m) = real(ri_sw(ib)); sri_sw(2, ib, l, m) = aimag(ri_sw(ib))
+        end do
+        do ib = 1, nlwbands
+          sri_lw(1, ib, l, m) = real(ri_lw(ib)); sri_lw(2, ib, l, m) = aimag(ri_lw(ib))
+        end do
+        select case (trim(spectype))                                                ! :783-833 (diagnostics only)
+        case ('sulfate');   spectype_c(l, m) = 0
+        case ('p-organic'); spectype_c(l, m) = 1
+        case ('s-organic'); spectype_c(l, m) = 2
+        case ('black-c');   spectype_c(l, m) = 3
+        case ('dust');      spectype_c(l, m) = 4
+        case ('seasalt');   spectype_c(l, m) = 5
+        end select
+      end do
+    end do
+
+    ! the engine must be up before tables can be uploaded; zm_convi normally did that already (re-initialising
+    ! later with the ZM namelist keeps the tables)
+    if (colphys_is_initialized() == 0) then
+      zp%cpair = cpair; zp%epsilo = epsilo; zp%gravit = gravit; zp%latice = latice; zp%latvap = latvap; zp%tmelt = tmelt
+      zp%rair = rair; zp%cpwv = cpwv; zp%cpliq = cpliq; zp%rh2o = rh2o; zp%cpvir = cpvir; zp%zvir = zvir
+      zp%c0_lnd = 0._r8; zp%c0_ocn = 0._r8; zp%ke = 0._r8; zp%ke_lnd = 0._r8; zp%momcu = 0._r8; zp%momcd = 0._r8
+      zp%tiedke_add = 0._r8; zp%capelmt = 70._r8; zp%dmpdz_param = -1.e-3_r8; zp%tau = 3600._r8
+      zp%limcnv = 1; zp%num_cin = 1; zp%zm_org = 0; zp%zmconv_microp = 0; zp%no_deep_pbl = 0; zp%lparcel_pbl = 0
+      call colphys_zm_params_defaults(zp)
+      rc = colphys_init(aero_device(), zp)
+      if (rc /= COLPHYS_OK) call endrun('modal_aer_opt_init (colphys): '//trim(colphys_error_message()))
+    end if
+
+    tb%nmodes = nmodes; tb%nspec_max = nspec_max; tb%nswbands = nswbands; tb%nlwbands = nlwbands
+    tb%top_lev = top_lev
+    tb%idx_sw_diag = idx_sw_diag; tb%idx_uv_diag = idx_uv_diag; tb%idx_nir_diag = idx_nir_diag
+    tb%rhoh2o = rhoh2o; tb%rga = rga; tb%rair = rair
+    tb%xrmin = log(0.01e-6_r8); tb%xrmax = log(25.e-6_r8)                            ! :140-143
+    tb%nspec = c_loc(nspec_m); tb%spectype = c_loc(spectype_c)
+    tb%sigmag = c_loc(sigmag); tb%specdens = c_loc(specdens); tb%hygro = c_loc(hygro)
+    tb%specrefindex_sw = c_loc(sri_sw); tb%specrefindex_lw = c_loc(sri_lw)
+    tb%refrtabsw = c_loc(refrsw); tb%refitabsw = c_loc(refisw); tb%refrtablw = c_loc(refrlw); tb%refitablw = c_loc(refilw)
+    tb%extpsw = c_loc(ext); tb%abspsw = c_loc(abss); tb%asmpsw = c_loc(asmp); tb%absplw = c_loc(abl)
+    tb%crefwsw = c_loc(cw_sw); tb%crefwlw = c_loc(cw_lw)
+    rc = colphys_aero_tables_set(tb)
+    if (rc /= COLPHYS_OK) call endrun('modal_aer_opt_init (colphys): '//trim(colphys_error_message()))
+  end subroutine modal_aer_opt_init
+
+  integer function aero_device()
+    ! one process per GPU: COLPHYS_DEVICE selects it (a launcher sets it to the node-local MPI rank)
+    character(len=16) :: env
+    integer :: stat, ndev
+    aero_device = 0
+    call get_environment_variable('COLPHYS_DEVICE', env, status=stat)
+    if (stat == 0) read(env, *, iostat=stat) aero_device
+    ndev = colphys_device_count()
+    if (ndev > 0) aero_device = mod(aero_device, ndev)
+  end function aero_device
+
+  !---------------------------------------------------------------------------------------------------------
+  subroutine read_water_refindex(infilename, cw_sw, cw_lw)
+    ! modal_aer_opt.F90:1475-1534: band counts checked against radconstants, four variables read; the imaginary
+    ! part enters with its absolute value (:1525-1530)
+    character(len=*), intent(in) :: infilename
+    real(r8), intent(out) :: cw_sw(2, nswbands), cw_lw(2, nlwbands)
+    type(file_desc_t) :: ncid
+    type(var_desc_t)  :: vid
+    integer :: ierr, did, dimlen
+    real(r8) :: re_sw(nswbands), im_sw(nswbands), re_lw(nlwbands), im_lw(nlwbands)
+
+    call cam_pio_openfile(ncid, infilename, PIO_NOWRITE)
+    ierr = pio_inq_dimid(ncid, 'lw_band', did)
+    ierr = pio_inq_dimlen(ncid, did, dimlen)
+    if (dimlen /= nlwbands) then
+      write(iulog,*) 'lw_band len=', dimlen, ' from ', infilename, ' ne nlwbands=', nlwbands
+      call endrun('read_modal_optics: bad lw_band value')
+    end if
+    ierr = pio_inq_dimid(ncid, 'sw_band', did)
+    ierr = pio_inq_dimlen(ncid, did, dimlen)
+    if (dimlen /= nswbands) then
+      write(iulog,*) 'sw_band len=', dimlen, ' from ', infilename, ' ne nswbands=', nswbands
+      call endrun('read_modal_optics: bad sw_band value')
+    end if
+    ierr = pio_inq_varid(ncid, 'refindex_real_water_sw', vid); ierr = pio_get_var(ncid, vid, re_sw)
+    ierr = pio_inq_varid(ncid, 'refindex_im_water_sw', vid);   ierr = pio_get_var(ncid, vid, im_sw)
+    ierr = pio_inq_varid(ncid, 'refindex_real_water_lw', vid); ierr = pio_get_var(ncid, vid, re_lw)
+    ierr = pio_inq_varid(ncid, 'refindex_im_water_lw', vid);   ierr = pio_get_var(ncid, vid, im_lw)
+    cw_sw(1,:) = re_sw; cw_sw(2,:) = abs(im_sw)
+    cw_lw(1,:) = re_lw; cw_lw(2,:) = abs(im_lw)
+    call pio_closefile(ncid)
+  end subroutine read_water_refindex
+
+  !---------------------------------------------------------------------------------------------------------
+  ! the chunk's inputs in the host layout of the *_chunks entry points (one chunk: (pcols,pver[,nspec_max],nmodes))
+  subroutine marshal_inputs(routine, list_idx, state, pbuf, pdeldry, specmmr, dgnumwet, qaerwat)
+    character(len=*), intent(in) :: routine
+    integer, intent(in) :: list_idx
+    type(physics_state), intent(in), target :: state
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    real(c_double), intent(out) :: pdeldry(pcols, pver), specmmr(pcols, pver, nspec_max, nmodes_clim)
+    real(c_double), intent(out) :: dgnumwet(pcols, pver, nmodes_clim), qaerwat(pcols, pver, nmodes_clim)
+    real(r8), pointer :: dgnumwet_m(:,:,:), qaerwat_m(:,:,:), mmr(:,:)
+    integer :: ncol, m, l
+
+    if (list_idx /= 0) call endrun(routine//' (colphys): diagnostic radiation lists (list_idx > 0) are not offloaded')
+    if (nmodes_clim <= 0) call endrun(routine//' (colphys): modal_aer_opt_init has not been called')
+    ncol = state%ncol
+    call pbuf_get_field(pbuf, dgnumwet_idx, dgnumwet_m)                              ! :679-681 / :1320-1322
+    call pbuf_get_field(pbuf, qaerwat_idx,  qaerwat_m)
+    pdeldry = 1._r8; specmmr = 0._r8; dgnumwet = 1.e-7_r8; qaerwat = 0._r8           ! padding is never read back
+    pdeldry(:ncol, :) = state%pdeldry(:ncol, :)
+    do m = 1, nmodes_clim
+      dgnumwet(:ncol, :, m) = dgnumwet_m(:ncol, :, m)
+      qaerwat(:ncol, :, m)  = qaerwat_m(:ncol, :, m)
+      do l = 1, nspec_m(m)
+        call rad_cnst_get_aer_mmr(list_idx, m, l, 'a', state, pbuf, mmr)            ! :759 / :1353
+        specmmr(:ncol, :, l, m) = mmr(:ncol, :)
+      end do
+    end do
+  end subroutine marshal_inputs
+
+  subroutine check_status(routine, lchnk, ncol, status, msg)
+    ! the reference aborts on an optical depth outside its sanity range (:997-1029, :1402-1437)
+    character(len=*), intent(in) :: routine, msg
+    integer, intent(in) :: lchnk, ncol
+    integer(c_int32_t), intent(in) :: status(pcols)
+    integer :: i
+    do i = 1, ncol
+      if (iand(status(i), COLPHYS_STATUS_DOPAER_RANGE) /= 0) then
+        write(iulog,*) routine//': dopaer out of range in chunk', lchnk, ' column', i
+        call endrun(msg)
+      end if
+    end do
+  end subroutine check_status
+
+  !---------------------------------------------------------------------------------------------------------
+  subroutine modal_aero_sw(list_idx, state, pbuf, nnite, idxnite, tauxar, wa, ga, fa)
+    ! modal_aer_opt.F90:485-1212 (radiative properties; the night-column list only masks history fields there)
+    integer,             intent(in) :: list_idx
+    type(physics_state), intent(in), target :: state
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    integer,             intent(in) :: nnite
+    integer,             intent(in) :: idxnite(nnite)
+    real(r8), intent(out), target :: tauxar(pcols,0:pver,nswbands)
+    real(r8), intent(out), target :: wa(pcols,0:pver,nswbands)
+    real(r8), intent(out), target :: ga(pcols,0:pver,nswbands)
+    real(r8), intent(out), target :: fa(pcols,0:pver,nswbands)
+
+    real(c_double), allocatable, target :: pdeldry(:,:), specmmr(:,:,:,:), dgnumwet(:,:,:), qaerwat(:,:,:)
+    integer(c_int32_t), target :: status(pcols)
+    integer(c_int32_t) :: ncol_c(1)
+    type(colphys_modal_aero_io) :: io
+    integer :: rc
+
+    allocate(pdeldry(pcols,pver), specmmr(pcols,pver,max(nspec_max,1),max(nmodes_clim,1)), &
+             dgnumwet(pcols,pver,max(nmodes_clim,1)), qaerwat(pcols,pver,max(nmodes_clim,1)))
+    call marshal_inputs('modal_aero_sw', list_idx, state, pbuf, pdeldry, specmmr, dgnumwet, qaerwat)
+    status = 0
+    io%pdeldry = c_loc(pdeldry); io%pmid = c_null_ptr; io%t = c_null_ptr
+    io%specmmr = c_loc(specmmr); io%dgnumwet = c_loc(dgnumwet); io%qaerwat = c_loc(qaerwat)
+    io%troplevchem = c_null_ptr
+    io%tauxar = c_loc(tauxar); io%wa = c_loc(wa); io%ga = c_loc(ga); io%fa = c_loc(fa)
+    io%status = c_loc(status)
+    ncol_c(1) = state%ncol
+    rc = colphys_modal_aero_sw_chunks(1, pcols, pver, ncol_c, io)
+    if (rc /= COLPHYS_OK) call endrun('modal_aero_sw (colphys): '//trim(colphys_error_message()))
+    call check_status('modal_aero_sw', state%lchnk, state%ncol, status, 'exit from modal_aero_sw')
+  end subroutine modal_aero_sw
+
+  !---------------------------------------------------------------------------------------------------------
+  subroutine modal_aero_lw(list_idx, state, pbuf, tauxar)
+    ! modal_aer_opt.F90:1216-1469
+    integer,             intent(in)  :: list_idx
+    type(physics_state), intent(in), target :: state
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    real(r8), intent(out), target :: tauxar(pcols,pver,nlwbands)
+
+    real(c_double), allocatable, target :: pdeldry(:,:), specmmr(:,:,:,:), dgnumwet(:,:,:), qaerwat(:,:,:)
+    integer(c_int32_t), target :: status(pcols)
+    integer(c_int32_t) :: ncol_c(1)
+    type(colphys_modal_aero_io) :: io
+    integer :: rc
+
+    allocate(pdeldry(pcols,pver), specmmr(pcols,pver,max(nspec_max,1),max(nmodes_clim,1)), &
+             dgnumwet(pcols,pver,max(nmodes_clim,1)), qaerwat(pcols,pver,max(nmodes_clim,1)))
+    call marshal_inputs('modal_aero_lw', list_idx, state, pbuf, pdeldry, specmmr, dgnumwet, qaerwat)
+    status = 0
+    io%pdeldry = c_loc(pdeldry); io%pmid = c_null_ptr; io%t = c_null_ptr
+    io%specmmr = c_loc(specmmr); io%dgnumwet = c_loc(dgnumwet); io%qaerwat = c_loc(qaerwat)
+    io%troplevchem = c_null_ptr
+    io%tauxar = c_loc(tauxar); io%wa = c_null_ptr; io%ga = c_null_ptr; io%fa = c_null_ptr
+    io%status = c_loc(status)
+    ncol_c(1) = state%ncol
+    rc = colphys_modal_aero_lw_chunks(1, pcols, pver, ncol_c, io)
+    if (rc /= COLPHYS_OK) call endrun('modal_aero_lw (colphys): '//trim(colphys_error_message()))
+    call check_status('modal_aero_lw', state%lchnk, state%ncol, status, 'exit from modal_aero_lw')
+  end subroutine modal_aero_lw
+
+end module AER_MODULE

@@ -97,6 +97,7 @@ void colphys_zm_params_defaults(colphys_zm_params *p);
 int  colphys_abi_version(void);
 const char *colphys_last_error(void);
 int  colphys_device_count(void);
+int  colphys_is_initialized(void);        /* 1 after a successful colphys_init, 0 before / after colphys_finalize */
 
 /* Select the HIP device of this process (one process per GPU) and upload parameters; builds the
  * 1-K saturation table zm_conv_evap's qsat uses.  May be called again to change parameters. */

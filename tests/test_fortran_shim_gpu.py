@@ -58,3 +58,21 @@ def test_fortran_caller_on_hip_engine_matches_reference_golden(name):
     ct = f.convtran(cq, cf, g["zm_mu"], g["zm_md"], g["zm_du"], g["zm_eu"], g["zm_ed"], g["zm_dp"], cdp, g["zm_jt"], g["zm_maxg"],
                     g["zm_ideep"], g["zm_lengath"], cases.DOCONVTRAN, cases.ISDRY, synth.ZTODT)
     assert_close("convtran.dqdt", ct, g["ct_dqdt"])
+
+
+@pytest.mark.parametrize("name", cases.AERO_GOLDEN)
+def test_fortran_optics_caller_on_hip_engine_matches_reference_golden(name):
+    """`module modal_aer_opt` built from the shim, driven by the caller source that drives the reference's module
+    (oracle/ref_wrap_aero.F90: tables served through the rad_constituents / pbuf / pio accessors, chunk loop,
+    modal_aer_opt_init / modal_aero_sw / modal_aero_lw with the reference's argument lists)."""
+    g = cases.load_golden(name)
+    n, pver = g["in_t"].shape
+    f = shim(pver)
+    f.aero_tables_set(synth.make_aero_props(int(g["seed"])), synth.PHYSCONST)   # -> modal_aer_opt_init of the shim
+    st = {k: g["in_" + k] for k in ("pdeldry", "pmid", "t")}
+    aer = {k: g["in_" + k] for k in ("specmmr", "dgnumwet", "qaerwat", "troplevchem")}
+    sw = f.modal_aero_sw(st, aer)
+    for k in ("tauxar", "wa", "ga", "fa"):
+        assert_close("modal_aero_sw." + k, sw[k], g["sw_" + k])
+    lw = f.modal_aero_lw(st, aer)
+    assert_close("modal_aero_lw.tauxar", lw["tauxar"], g["lw_tauxar"])
