@@ -465,6 +465,14 @@ int colphys_aero_tables_set(const colphys_aero_tables *tb)
         bad |= pack(3, sw_t, tb->refrtabsw, tb->refitabsw, nsw, &A.slices_sw);
         bad |= pack(1, lw_t, tb->refrtablw, tb->refitablw, nlw, &A.slices_lw);
     }
+    {
+        std::vector<double> e(nm);
+        for (size_t m = 0; m < nm; ++m) {
+            const double alnsg = std::log(tb->sigmag[m]);
+            e[m] = std::exp(2.0 * alnsg * alnsg);
+        }
+        bad |= up(e.data(), 8 * nm, (const void **)&A.explnsigma);
+    }
     if (bad) return fail(COLPHYS_ERR_HIP, "uploading packed aerosol table slices failed");
     g_aero_set = true;
     return COLPHYS_OK;

@@ -47,6 +47,7 @@ struct AeroDev {
     // packed per-(mode, band) table slices = the LDS image the optics kernels stage (built by colphys_aero_tables_set):
     // ntab x [PREFI*PREFR corners][AERO_NCP] coefficients (5 + zero pad), refr[PREFR], refi[PREFI], zero fill to 1 KiB
     const double *slices_sw, *slices_lw;
+    const double *explnsigma;       // [nmodes] exp(2 ln(sigmag)^2), modal_aer_opt.F90:1553-1554
 };
 constexpr int AERO_NCP = 6;
 constexpr int AERO_TBLP = COLPHYS_PREFI * COLPHYS_PREFR * AERO_NCP;

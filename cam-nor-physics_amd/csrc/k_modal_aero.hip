@@ -104,13 +104,12 @@ __device__ __forceinline__ double interp_cheb(const double *tbl, const Wght &wr,
     return p;
 }
 
-__device__ __forceinline__ void size_parameters(const AeroDev &A, double sigma_logr_aer, double dgnumwet, double &radsurf,
+__device__ __forceinline__ void size_parameters(const AeroDev &A, double explnsigma, double dgnumwet, double &radsurf,
                                                 double &logradsurf, double *cheb)
-{   // :1553-1570
-    const double alnsg_amode = log(sigma_logr_aer);
-    const double explnsigma = exp(2.0 * alnsg_amode * alnsg_amode);
+{   // :1553-1570.  explnsigma = exp(2 ln(sigma_g)^2) is a per-mode constant (:1553-1554): evaluated once on the host
+    // when the tables are set, not per cell
     radsurf = 0.5 * dgnumwet * explnsigma;
-    logradsurf = log(radsurf);
+    logradsurf = cp_log(radsurf);
     double xrad = fmax(logradsurf, A.xrmin);
     xrad = fmin(xrad, A.xrmax);
     xrad = (2.0 * xrad - A.xrmax - A.xrmin) / (A.xrmax - A.xrmin);
@@ -182,7 +181,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
             vol[l] = 0.0;
             if (l < nspec) vol[l] = io.specmmr[((size_t)m * A.nspec_max + l) * F + cc];
         }
-        size_parameters(A, as_const(A.sigmag)[m], dgn, radsurf, logradsurf, cheb);
+        size_parameters(A, as_const(A.explnsigma)[m], dgn, radsurf, logradsurf, cheb);
 #pragma unroll
         for (int l = 0; l < NSMAX; ++l) {                               // :764-766
             if (l < nspec) {
