@@ -457,6 +457,15 @@ int colphys_aero_tables_set(const colphys_aero_tables *tb)
             double *g = o + (size_t)ntab * AERO_TBLP;
             for (int j = 0; j < COLPHYS_PREFR; ++j) g[j] = refr[u * COLPHYS_PREFR + j];
             for (int j = 0; j < COLPHYS_PREFI; ++j) g[COLPHYS_PREFR + j] = refi[u * COLPHYS_PREFI + j];
+            double *r = g + COLPHYS_PREFR + COLPHYS_PREFI;       // reciprocal widths, table_interp's |dx| > 1e-20 guard
+            for (int j = 0; j + 1 < COLPHYS_PREFR; ++j) {
+                const double dx = g[j + 1] - g[j];
+                r[j] = std::fabs(dx) > 1.e-20 ? 1.0 / dx : 0.0;
+            }
+            for (int j = 0; j + 1 < COLPHYS_PREFI; ++j) {
+                const double dx = g[COLPHYS_PREFR + j + 1] - g[COLPHYS_PREFR + j];
+                r[COLPHYS_PREFR + j] = std::fabs(dx) > 1.e-20 ? 1.0 / dx : 0.0;
+            }
         }
         return up(h.data(), h.size() * sizeof(double), (const void **)dst);
     };

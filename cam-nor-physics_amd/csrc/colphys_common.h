@@ -45,7 +45,8 @@ struct AeroDev {
     const double *sigmag, *specdens, *hygro, *specrefindex_sw, *specrefindex_lw;
     const double *refrtabsw, *refitabsw, *refrtablw, *refitablw, *extpsw, *abspsw, *asmpsw, *absplw, *crefwsw, *crefwlw;
     // packed per-(mode, band) table slices = the LDS image the optics kernels stage (built by colphys_aero_tables_set):
-    // ntab x [PREFI*PREFR corners][AERO_NCP] coefficients (5 + zero pad), refr[PREFR], refi[PREFI], zero fill to 1 KiB
+    // ntab x [PREFI*PREFR corners][AERO_NCP] coefficients (5 + zero pad), refr[PREFR], refi[PREFI], the reciprocal
+    // interval widths rdxr[PREFR], rdxi[PREFI] (0 where the interval is degenerate and for the last point), zero fill to 1 KiB
     const double *slices_sw, *slices_lw;
     const double *explnsigma;       // [nmodes] exp(2 ln(sigmag)^2), modal_aer_opt.F90:1553-1554
 };
@@ -53,7 +54,7 @@ constexpr int AERO_NCP = 6;
 constexpr int AERO_TBLP = COLPHYS_PREFI * COLPHYS_PREFR * AERO_NCP;
 constexpr int aero_slice_doubles(int ntab)
 {
-    return ((ntab * AERO_TBLP + COLPHYS_PREFR + COLPHYS_PREFI) * 8 + 1023) / 1024 * 128;
+    return ((ntab * AERO_TBLP + 2 * (COLPHYS_PREFR + COLPHYS_PREFI)) * 8 + 1023) / 1024 * 128;
 }
 
 // ---- logarithms -----------------------------------------------------------------------------------------

@@ -56,18 +56,19 @@ __device__ __forceinline__ cptr_t as_const(const double *p) { return (cptr_t)(co
 
 // calcwghts of table_interp: first grid point above x (the reference's loop with exit), extrapolating below the
 // grid and clamping above it.  g: the grid through a wave-uniform global pointer (scalar loads -> SGPR operands);
-// s_g: the same grid in LDS for the two data-dependent reads.
+// s_g / s_rdx: the same grid and the reciprocal widths 1/(g[j+1]-g[j]) of its intervals in LDS (packed with the
+// slice on the host; 0 for a degenerate interval and past the last point, which reproduces the reference's
+// `t = 0 when |dx| <= 1e-20`) for the two data-dependent reads.  t = (x-x1)*rdx differs from the reference's
+// (x-x1)/dx in the last bit at most.
 template <int N>
-__device__ __forceinline__ Wght calcwghts(cptr_t g, const double *s_g, double x)
+__device__ __forceinline__ Wght calcwghts(cptr_t g, const double *s_g, const double *s_rdx, double x)
 {
     int ii = N + 1;
 #pragma unroll
     for (int j = N; j >= 1; --j) ii = (x < g[j - 1]) ? j : ii;
     const int ix1 = max(ii - 1, 1), ix2 = min(ix1 + 1, N);
-    const double x1 = s_g[ix1 - 1], x2 = s_g[ix2 - 1];
-    const double dx = x2 - x1;
-    double t = (x - x1) / dx;
-    t = (fabs(dx) > 1.e-20) ? t : 0.0;
+    const double x1 = s_g[ix1 - 1], rdx = s_rdx[ix1 - 1];
+    const double t = (x - x1) * rdx;
     Wght w;
     w.wt1 = 1.0 - t; w.wt2 = t; w.ix1 = ix1 - 1; w.ix2 = ix2 - 1;
     return w;
@@ -194,13 +195,15 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
         if (watervol < 0.0) { watervol = 0.0; wetvol = dryvol; }
         const bool small = logradsurf <= A.xrmax;
         const double pext_large = 1.5 / (radsurf * A.rhoh2o);           // :875
-        const double wetdiv = SW ? fmax(wetvol, 1.e-60) : wetvol;
+        // cre/wetvol, cim/wetvol (:850 / :1377) as products with one reciprocal per (cell, mode): last-bit difference
+        const double wetinv = 1.0 / (SW ? fmax(wetvol, 1.e-60) : wetvol);
 
         for (int jb = 0; jb < nbg; ++jb, ++unit) {                      // :726 / :1343
             const int ib = b0 + jb;
             const double *s_tbl = s_slice0 + cur * SLICE;
             const double *s_refr = s_tbl + NTAB * TBLP;
             const double *s_refi = s_refr + NR;
+            const double *s_rdxr = s_refi + NI, *s_rdxi = s_rdxr + NR;
             const size_t gsl = (size_t)m * nb + ib;
             // the next (mode, band) slice starts its way into the other buffer
             if (unit + 1 < nunits) {
@@ -223,17 +226,17 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
             cim = cim + watervol * crefw[1];
             double refr, refi;
             if (SW) {
-                cre = cre / wetdiv;
-                cim = cim / wetdiv;
+                cre = cre * wetinv;
+                cim = cim * wetinv;
                 refr = cre; refi = fabs(cim);
             } else {
-                const double qr = cre / wetdiv, qi = cim / wetdiv;
+                const double qr = cre * wetinv, qi = cim * wetinv;
                 const bool dv = wetvol > 1.e-40;
                 refr = dv ? qr : cre; refi = dv ? qi : cim;
             }
             cptr_t g_grid = as_const(slices + gsl * SLICE + NTAB * TBLP);   // uniform -> scalar loads
-            const Wght wr = calcwghts<NR>(g_grid, s_refr, refr);        // :857-858 / :1383-1384
-            const Wght wi = calcwghts<NI>(g_grid + NR, s_refi, refi);
+            const Wght wr = calcwghts<NR>(g_grid, s_refr, s_rdxr, refr);        // :857-858 / :1383-1384
+            const Wght wi = calcwghts<NI>(g_grid + NR, s_refi, s_rdxi, refi);
 
             if (SW) {
                 double pext = interp_cheb(s_tbl, wr, wi, cheb);         // :860, 870-873
