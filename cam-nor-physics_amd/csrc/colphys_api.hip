@@ -220,6 +220,7 @@ int colphys_init(int device, const colphys_zm_params *p)
     P.tfreez = p->tmelt; P.eps1 = p->epsilo; P.rl = p->latvap; P.cpres = p->cpair; P.rgrav = 1.0 / p->gravit;
     P.rgas = p->rair; P.grav = p->gravit; P.cp = P.cpres; P.dcol = (p->cpliq - p->cpwv) / p->latvap;
     P.omeps = 1.0 - p->epsilo;
+    P.ln_tfreez = std::log(P.tfreez);
     P.limcnv = p->limcnv; P.num_cin = p->num_cin; P.zm_org = p->zm_org; P.no_deep_pbl = p->no_deep_pbl;
     P.lparcel_pbl = p->lparcel_pbl;
 

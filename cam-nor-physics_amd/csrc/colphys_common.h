@@ -30,6 +30,7 @@ struct ZmDev {
     double tiedke_lnd, entrmn, alfadet, tentrm, plclmin, cin_threshd, parcel_hscale;
     // derived
     double rl, cpres, rgrav, rgas, grav, cp, tfreez, eps1, dcol, omeps;
+    double ln_tfreez;               // ln(tfreez), host libm at init
     int limcnv, num_cin, zm_org, no_deep_pbl, lparcel_pbl;
 };
 

@@ -68,12 +68,20 @@ __device__ __forceinline__ double enthalpy_d(const ZmDev &P, double TK, double p
 
 // ientropy :5304-5414 (KIND 0) / ienthalpy :5460-5570 (KIND 1): Brent's method, bracket Tfg +- 10 K.
 //
-// Same iteration, same arithmetic per evaluation as the reference; three EXACT savings (identical bits):
+// Same iteration as the reference.  The function evaluation is where the ascent's instructions go (~9 evaluations
+// per inversion, 3-4 inversions per level), so it is written for instruction count:
 //  (1) qst(T) is carried with every bracket point, so the reference's closing `qsat_hPa(T)` (:5399, :5555) --
-//      a re-evaluation at a temperature that was already evaluated -- is a register move;
+//      a re-evaluation at a temperature that was already evaluated -- is a register move (identical bits);
 //  (2) entropy: while the parcel is unsaturated at the trial temperature (qv = qt) the term
-//      log((p - e)/pref) does not depend on T: it is computed once per inversion and reused;
-//  (3) entropy: when saturated, qv = qst and log(qv/qst) = log(1) = 0 exactly: the logarithm is skipped.
+//      log((p - e)/pref) does not depend on T: it is computed once per inversion and reused (identical bits);
+//  (3) entropy: when saturated, qv = qst and log(qv/qst) = log(1) = 0 exactly: the logarithm is skipped;
+//  (4) ONE reciprocal of the trial temperature serves the whole evaluation, and divisions by constants are
+//      products: Tboil/T = Tboil*(1/T), L qv/T = L qv (1/T), T/Tboil = T*(1/Tboil), T/Tfreez = T*(1/Tfreez),
+//      x/1000 = x*0.001.  Each differs from the reference's quotient by at most one unit in the last place of
+//      that intermediate (|error| of the entropy ~1e-13 J/kg/K) -- the same class of difference as OCML vs the
+//      host libm.  (Sharing one ln T between log(T/Tfreez) and log10(Tboil/T) was tried and rejected: it costs
+//      ~5e-13 in the entropy, enough to flip Brent's sign tests near the root on ~1 column in 1000 and move CAPE
+//      by 1.5e-10.)
 #ifndef BRENT_INLINE
 #define BRENT_INLINE __forceinline__
 #endif
@@ -94,12 +102,22 @@ __device__ BRENT_INLINE int invert_brent(const ZmDev &P, double s, double p, dou
         const double e_unsat = qt * p / (P.eps1 + qt);
         lg_unsat = cp_log((p - e_unsat) / 1000.0);
     }
+    const double pPa = p * 100.0;              // qsat_hPa :5430
+    const double RTBOIL = 1.0 / 373.16, rtfreez = 1.0 / P.tfreez;
 
     auto feval = [&](double TK, double &qs_out) -> double {
-        const double L = P.rl - (P.cpliq - P.cpwv) * (TK - P.tfreez);
-        double est, qs;
-        qsat_hPa(P, TK, p, est, qs);
+        const double rt = 1.0 / TK;
+        // Goff-Gratch over water (svp_water_gg, colphys_common.h) on the shared 1/T
+        const double u = 373.16 * rt;
+        const double es = exp10(-7.90298 * (u - 1.0) + 5.02808 * cp_log10(u)
+                                - 1.3816e-7 * (exp10(11.344 * (1.0 - TK * RTBOIL)) - 1.0)
+                                + 8.1328e-3 * (exp10(-3.49149 * (u - 1.0)) - 1.0)
+                                + 3.0057148979490314) * 100.0;
+        double qs;                             // qsat_water: qs = eps es / (p - (1-eps) es), 1 where p <= es
+        if ((pPa - es) <= 0.0) qs = 1.0;
+        else qs = P.epsilo * es / (pPa - P.omeps * es);
         qs_out = qs;
+        const double L = P.rl - (P.cpliq - P.cpwv) * (TK - P.tfreez);
         const double qv = fmin(qt, qs);
         if (KIND == 1) return ((P.cpres + qt * P.cpliq) * TK + L * qv + (1.0 + qt) * P.grav * z) - s;       // :5454
         double lgp, lgq;
@@ -108,10 +126,10 @@ __device__ BRENT_INLINE int invert_brent(const ZmDev &P, double s, double p, dou
             lgq = cp_log(qv / qs);
         } else {                               // saturated: qv = qs
             const double e = qv * p / (P.eps1 + qv);
-            lgp = cp_log((p - e) / 1000.0);
+            lgp = cp_log((p - e) * 0.001);
             lgq = 0.0;                         // log(qs/qs)
         }
-        return ((P.cpres + qt * P.cpliq) * cp_log(TK / P.tfreez) - P.rgas * lgp + L * qv / TK - qv * P.rh2o * lgq) - s;   // :5297
+        return ((P.cpres + qt * P.cpliq) * cp_log(TK * rtfreez) - P.rgas * lgp + L * qv * rt - qv * P.rh2o * lgq) - s;   // :5297
     };
 
     a = Tfg - 10;
