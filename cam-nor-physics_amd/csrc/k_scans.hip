@@ -28,7 +28,7 @@ __device__ __forceinline__ int ldk_of(int nlev) { return (nlev & 1) ? nlev : nle
 __device__ __forceinline__ void tile_in(double *s, const double *g, int nc, int nlev, int ldk)
 {
     const int n = nc * nlev;
-    for (int i = threadIdx.x; i < n; i += NT) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int c = i / nlev, k = i - c * nlev;
         s[c * ldk + k] = g[i];
     }
@@ -36,7 +36,7 @@ __device__ __forceinline__ void tile_in(double *s, const double *g, int nc, int 
 __device__ __forceinline__ void tile_out(double *g, const double *s, int nc, int nlev, int ldk)
 {
     const int n = nc * nlev;
-    for (int i = threadIdx.x; i < n; i += NT) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int c = i / nlev, k = i - c * nlev;
         g[i] = s[c * ldk + k];
     }
@@ -53,8 +53,9 @@ __device__ __forceinline__ void tile_out(double *g, const double *s, int nc, int
 //   LDS = 2 tiles: 34 KB for 64 columns x L32 => 4 blocks per CU; all 64 lanes scan.
 // ------------------------------------------------------------------------------------------------------
 constexpr int GT = 64;        // columns per block
+constexpr int GNT = 256;      // threads per block: four waves move data (8 flat-index steps at L32), one wave scans
 
-__global__ __launch_bounds__(NT) void geopotential_kernel(int ncol, int pver, int dycore_kind, int nspecies,
+__global__ __launch_bounds__(GNT) void geopotential_kernel(int ncol, int pver, int dycore_kind, int nspecies,
                                                          const double *__restrict__ piln, const double *__restrict__ pint,
                                                          const double *__restrict__ pmid, const double *__restrict__ pdel,
                                                          const double *__restrict__ rpdel, const double *__restrict__ t,
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(NT) void geopotential_kernel(int ncol, int pver, in
     double *sZM = smem + GT * ldp;        // [GT][ldp]: dzm(k), then zm(k)
 
     const int n = nc * pver;
-    for (int i = threadIdx.x; i < n; i += NT) {
+    for (int i = threadIdx.x; i < n; i += GNT) {
         const int c = i / pver, k = i - c * pver;              // 0-based level
         const size_t g = col0 * L + i;                         // flat index, mid-level fields
         const size_t gi = (size_t)(col0 + c) * LP + k;         // flat index, interface fields
@@ -114,11 +115,11 @@ __global__ __launch_bounds__(NT) void geopotential_kernel(int ncol, int pver, in
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nc * pverp; i += NT) {
+    for (int i = threadIdx.x; i < nc * pverp; i += GNT) {
         const int cc = i / pverp, k = i - cc * pverp;
         zi[col0 * LP + i] = sZI[cc * ldp + k];
     }
-    for (int i = threadIdx.x; i < n; i += NT) {
+    for (int i = threadIdx.x; i < n; i += GNT) {
         const int cc = i / pver, k = i - cc * pver;
         zm[col0 * L + i] = sZM[cc * ldp + k];
     }
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(NT) void geopotential_kernel(int ncol, int pver, in
 // ------------------------------------------------------------------------------------------------------
 // zm_conv_evap (old_snow path; kemask = ke unless zm_org)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void zm_conv_evap_kernel(ZmDev P, const double *__restrict__ estbl, int ncol, int pver,
+constexpr int ENT = 256;      // threads per block: four waves move the tiles (4 flat-index steps per tile at L32), 32 lanes scan
+__global__ __launch_bounds__(ENT) void zm_conv_evap_kernel(ZmDev P, const double *__restrict__ estbl, int ncol, int pver,
                                                          double deltat, colphys_zm_conv_evap_io io)
 {
     CHAIN_PRIO();
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(NT) void zm_conv_evap_kernel(ZmDev P, const double 
     double *sFP = sCL + TILE * ld;     // flxprec [ldp]
     double *sFS = sFP + TILE * ldp;    // flxsnow [ldp]
 
-    for (int i = threadIdx.x; i <= COLPHYS_PLENEST; i += NT) s_estbl[i] = estbl[i];
+    for (int i = threadIdx.x; i <= COLPHYS_PLENEST; i += ENT) s_estbl[i] = estbl[i];
     tile_in(sT, io.t + col0 * L, nc, pver, ld);
     tile_in(sPM, io.pmid + col0 * L, nc, pver, ld);
     tile_in(sPD, io.pdel + col0 * L, nc, pver, ld);
@@ -383,7 +385,7 @@ int launch_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspec
     const size_t lds = (size_t)GT * 2 * ldp * sizeof(double);
     if (set_lds((const void *)geopotential_kernel, lds)) return COLPHYS_ERR_HIP;
     const int nblk = (ncol + GT - 1) / GT;
-    hipLaunchKernelGGL(geopotential_kernel, dim3(nblk), dim3(NT), lds, st, ncol, pver, dycore_kind, nspecies, piln, pint,
+    hipLaunchKernelGGL(geopotential_kernel, dim3(nblk), dim3(GNT), lds, st, ncol, pver, dycore_kind, nspecies, piln, pint,
                        pmid, pdel, rpdel, t, q, rair, gravit, zvir, zi, zm);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
@@ -396,7 +398,7 @@ int launch_zm_conv_evap(const ZmDev &P, const double *estbl_dev, int ncol, int p
     if (lds > 150 * 1024) return COLPHYS_ERR_UNSUPPORTED;
     if (set_lds((const void *)zm_conv_evap_kernel, lds)) return COLPHYS_ERR_HIP;
     const int nblk = (ncol + TILE - 1) / TILE;
-    hipLaunchKernelGGL(zm_conv_evap_kernel, dim3(nblk), dim3(NT), lds, st, P, estbl_dev, ncol, pver, deltat, io);
+    hipLaunchKernelGGL(zm_conv_evap_kernel, dim3(nblk), dim3(ENT), lds, st, P, estbl_dev, ncol, pver, deltat, io);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
 
