@@ -1,7 +1,7 @@
 // k_momtran.hip -- convective momentum transport, /root/reference/physics/zm_conv.F90:2315-2715, for gfx950.
 //
 // Only the gathered (deep) columns do work -- a few thousand of 48 602 -- so the mapping is ONE WAVE PER
-// GATHERED COLUMN with the lanes along the vertical:
+// GATHERED COLUMN with the lanes along the vertical (one block per host chunk walks the chunk's gathered rows):
 //   - the column's profiles (winds, mass fluxes, layer thickness) are read as contiguous rows into LDS;
 //   - everything that is element-wise in k (interface winds, pressure-gradient terms, tendencies, momentum
 //     flux, end-of-step winds, KE dissipation) runs one level per lane;
@@ -21,10 +21,9 @@ __global__ __launch_bounds__(NT) void momtran_wave_kernel(ZmDev P, int ncol, int
 {
     CHAIN_PRIO();
     extern __shared__ double smem[];
-    const int row = blockIdx.x;                               // gathered row of the flat layout
-    const int ic = row / pcols, c0 = ic * pcols, slot = row - c0;
+    const int ic = blockIdx.x, c0 = ic * pcols;               // one block per host chunk, looping over its gathered rows
     const int il2g = io.lengath[ic];
-    if (slot >= il2g) return;                                 // block-uniform
+    if (il2g <= 0) return;                                    // block-uniform
     const int lane = threadIdx.x;
     const int LD = pver + 2;                                  // 1-based profiles, [0] and [pver+1] as guards
     const size_t L = (size_t)pver, F = (size_t)ncol * L;
@@ -45,6 +44,8 @@ __global__ __launch_bounds__(NT) void momtran_wave_kernel(ZmDev P, int ncol, int
         ktm = min(ktm, io.jt[c0 + i]);
         kbm = min(kbm, io.mx[c0 + i]);
     }
+    for (int slot = 0; slot < il2g; ++slot) {
+    const int row = c0 + slot;                                // gathered row of the flat layout
     const size_t ii = (size_t)(c0 + io.ideep[row] - 1);
     const int mx = io.mx[row];
 
@@ -152,6 +153,8 @@ __global__ __launch_bounds__(NT) void momtran_wave_kernel(ZmDev P, int ncol, int
         }
         io.seten[ii * L + (k - 1)] = gset;
     }
+    __syncthreads();
+    }
 }
 
 // initialisation of the full-layout outputs (:2429-2443), element-wise
@@ -174,6 +177,7 @@ int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, con
     const int iblk = (int)((n2 + 255) / 256 < 2048 ? (n2 + 255) / 256 : 2048);
     hipLaunchKernelGGL(momtran_init_kernel, dim3(iblk), dim3(256), 0, st, n2, n1, io);
     const size_t lds = (size_t)(6 + 2 * 8) * (pver + 2) * sizeof(double);
-    hipLaunchKernelGGL(momtran_wave_kernel, dim3(ncol), dim3(NT), lds, st, P, ncol, pver, pcols, dt, io);
+    const int nchunks = (ncol + pcols - 1) / pcols;
+    hipLaunchKernelGGL(momtran_wave_kernel, dim3(nchunks), dim3(NT), lds, st, P, ncol, pver, pcols, dt, io);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
