@@ -5,13 +5,14 @@
 // Line numbers in comments are zm_conv.F90.
 //
 // Whole-node dispatch: one work item = one grid column, independent of how the host groups columns into
-// chunks.  Three launches per call:
+// chunks.  Five launches per call:
 //
 //   zm_trigger_kernel  every column : unit conversion, PBL-top index, first dilute-parcel ascent
 //                                     (buoyan_dilute/parcel_dilute), CAPE/CIN, trigger test; zero-fills the
 //                                     outputs; appends triggered columns to a device-side list.
-//   zm_plume_kernel    listed columns: cloud ensemble (cldprp), second parcel ascent with the ensemble's mean
-//                                     entrainment, re-trigger, cldprp again, closure, tendencies (q1q2_pjr),
+//   zm_plume1_kernel   listed columns, one wave each: cloud ensemble (cldprp) -> the ensemble's mean entrainment
+//   zm_ascent2_kernel  listed columns: second parcel ascent with that entrainment, re-trigger test
+//   zm_plume2_kernel   re-triggered columns, one wave each: cldprp again, closure, tendencies (q1q2_pjr),
 //                                     precipitation integrals; writes full-layout results.
 //   zm_gather_kernel   one block per host chunk: ascending-order compaction of the deep columns into the
 //                                     reference's per-chunk gathered layout (mu md du eu ed dp dsubcld jt maxg
@@ -19,10 +20,10 @@
 //
 // The dilute parcel is the cost (>= 84 % of the CPU time).  The reference makes two sweeps over
 // the levels (entrainment loop :4997-5148, then precipitation/freezing loop :5175-5273) through seven work
-// profiles; here the two sweeps are fused into ONE upward pass that carries the (k+1) values of both
-// sweeps in registers -- same arithmetic in the same order per level, no work profiles.  The only
-// profile the trigger needs afterwards is the parcel virtual temperature (for the neutral-buoyancy search
-// and the CAPE/CIN sums, :4773-4810); it is kept in LDS as [level][lane].
+// profiles; here the two sweeps run as a two-wave pipeline over the same 64 columns (buoyan_dilute_2w below), each
+// wave carrying the (k+1) values of its sweep in registers -- same arithmetic in the same order per level, no work
+// profiles.  The only profile the trigger needs afterwards is the parcel virtual temperature (for the
+// neutral-buoyancy search and the CAPE/CIN sums, :4773-4810); it is kept in LDS as [level][lane].
 //
 // Arithmetic: fp64, no FMA contraction (-ffp-contract=off), operation order of the reference.
 // Transcendentals are ROCm OCML (exp10/exp/pow) and the < 1 ulp logarithms of colphys_common.h: not
@@ -211,13 +212,30 @@ __device__ __forceinline__ double moist_static_energy_total(const ZmDev &P, doub
            + (P.rl - (P.cpliq - P.cpwv) * (t - P.tfreez)) * q;
 }
 
-// buoyan_dilute :4425-4819 with parcel_dilute :4824-5277 fused into one upward pass.
+// buoyan_dilute :4425-4819 with parcel_dilute :4824-5277, the two sweeps of the reference run as a TWO-WAVE PIPELINE.
+//
+// The ascent of a column is a chain that is strictly serial in the level index, and at ne30 size there are fewer
+// columns (48 602) than lanes on the chip, so a column's own latency is what the trigger costs.  The reference's two
+// sweeps over the levels -- sweep 1 (:4997-5148: entrainment, enthalpy inversion, LCL) and sweep 2 (:5175-5273: rain-out
+// and freezing, two entropy inversions per level) -- are coupled only one way: sweep 2 at level k needs sweep 1's
+// (tmix, qsmix, qtmix) of level k.  A block is therefore two waves over the same 64 columns (lane = column):
+//     wave A (role 0): sweep 1 of level k     + the entropy of the mixture that sweep 2 starts from     (1/3 of the work)
+//     wave B (role 1): sweep 2 of level k + 1 + parcel virtual temperature -> LDS profile               (2/3 of the work)
+// exchanging four doubles per (column, level) through a double-buffered LDS mailbox, one barrier per level.  Each wave
+// carries the (k+1) state of its own sweep in registers (no work profiles).  Same arithmetic per level as the fused
+// single-wave pass; the level loop is uniform over the block (lanes below their launch level are predicated off).
+// After the last level wave A hands its scalars (LCL index and pressure, parcel temperature at the LCL, status) to
+// wave B, which does buoyancy, neutral levels and the CAPE / CIN sums (:4742-4816).  Results are valid on wave B.
 //   dmpdz    : parcel entrainment rate (/m); level-uniform in both calls of the reference (:544, :1074)
 //   s_tpv    : LDS, element for level k at s_tpv[k*WAVE]  (caller passes base + lane)
-//   tp, qstp : optional 1-based outputs (parcel temperature / saturation mixing ratio), nullptr to skip
-template <bool STORE_TP>
-__device__ void buoyan_dilute_d(const ZmDev &P, const ColIn &c, double pblt, double dmpdz, double cin_in,
-                                double *s_tpv, double *tp, double *qstp, BuoyRes &r)
+//   s_mail   : LDS, MAIL_DOUBLES doubles for the block
+//   tp, qstp : optional 1-based outputs (parcel temperature / saturation mixing ratio), written where store_ok
+constexpr int MAIL_FIELDS = 4;
+constexpr int MAIL_DOUBLES = (2 * MAIL_FIELDS + 4) * WAVE;
+
+template <bool STORE_TP, bool PIPE>
+__device__ void buoyan_dilute_2w(const ZmDev &P, const ColIn &c, double pblt, double dmpdz, double cin_in, int role, int lane,
+                                 double *s_tpv, double *s_mail, double *tp, double *qstp, bool store_ok, BuoyRes &r)
 {
     const int pver = c.pver, msg = c.msg;
     const int npblt = (int)lrint(pblt);
@@ -231,6 +249,7 @@ __device__ void buoyan_dilute_d(const ZmDev &P, const ColIn &c, double pblt, dou
     r.cape = 0.0;
     r.cin = cin_in;
 
+    // launch level and launch parcel: both waves need them and both compute them (a few hundred instructions)
     double parcel_ztop = 0.0, hpar = 0.0, qpar = 0.0;
     if (P.lparcel_pbl) {                                            // :4586-4588, 4638-4673
         double pbl_dz = c.Z(npblt) - c.zs;
@@ -273,13 +292,13 @@ __device__ void buoyan_dilute_d(const ZmDev &P, const ColIn &c, double pblt, dou
     }
     pl = c.Pm(klaunch);
 
-    // ---- fused parcel_dilute ---------------------------------------------------------------------
-    double zl = 0.0, mp = 0.0, qtp = 0.0, sp = 0.0, sp0, qtp0, mp0;
-    double t_kp1, q_kp1, p_kp1, z_kp1;                 // environment at k+1
-    double tmix1_kp1, qsmix1_kp1, qtmix_kp1, smix1_kp1; // sweep-1 values at k+1
-    double xsh2o_kp1 = 0.0, ds_xsh2o_kp1 = 0.0, ds_freeze_kp1 = 0.0, qsmix2_kp1;   // sweep-2 values at k+1
-    {
-        const int k = klaunch;                                      // :5002-5038, 5180-5200
+    // ---- sweep 1 (:4997-5148): state and one level ------------------------------------------------------------
+    double zl = 0.0, mp = 0.0, qtp = 0.0, sp = 0.0, sp0 = 0.0, qtp0 = 0.0, mp0 = 1.0;
+    double t_kp1 = 0.0, q_kp1 = 0.0, p_kp1 = 0.0, z_kp1 = 0.0;                       // environment at k+1
+    double tmix1_kp1 = 0.0, qsmix1_kp1 = 0.0, qtmix_kp1 = 0.0, smix1_kp1 = 0.0;       // sweep-1 values at k+1
+    double t_nx = 0.0, q_nx = 0.0, pap_nx = 0.0, zm_nx = 0.0;                         // inputs of the next level
+    auto initA = [&]() {
+        const int k = klaunch;                                      // :5002-5038
         const double tk = c.T(k), qk = c.Q(k), pk = c.Pm(k), zk = c.Z(k);
         double est;
         if (P.lparcel_pbl) {
@@ -294,21 +313,17 @@ __device__ void buoyan_dilute_d(const ZmDev &P, const ColIn &c, double pblt, dou
         qtmix_kp1 = qtp0;
         tmix1_kp1 = tk;
         qsat_hPa(P, tmix1_kp1, pk, est, qsmix1_kp1);
-        qsmix2_kp1 = qsmix1_kp1;
         t_kp1 = tk; q_kp1 = qk; p_kp1 = pk; z_kp1 = zk;
-        const double tpk = tmix1_kp1, qstpk = qk;
-        s_tpv[k * WAVE] = (tpk + c.tpert) * (1.0 + qstpk / P.eps1) / (1.0 + qstpk);   // :5194
-        if (STORE_TP) { tp[k] = tpk; qstp[k] = qstpk; }
-    }
-    // The level loop is ~14 k instructions per iteration, so the four input values of the NEXT level are
-    // requested one iteration ahead: their (strided, usually L2-missing) loads complete under the Brent solves.
-    double t_nx = 0.0, q_nx = 0.0, pap_nx = 0.0, zm_nx = 0.0;
-    if (klaunch - 1 >= msg + 1) { t_nx = c.t[klaunch - 1]; q_nx = c.q[klaunch - 1]; pap_nx = c.pap[klaunch - 1]; zm_nx = c.zm[klaunch - 1]; }
-    for (int k = klaunch - 1; k >= msg + 1; --k) {
-        const double tk = t_nx, qk = q_nx, pk = pap_nx * 0.01, zk = zm_nx + c.zs;
+        // the four input values of the NEXT level are requested one level ahead: their (strided, usually L2-missing)
+        // loads complete under the Brent solves
+        const int kn = klaunch - 1;
+        if (kn >= msg + 1) { t_nx = c.t[kn]; q_nx = c.q[kn]; pap_nx = c.pap[kn]; zm_nx = c.zm[kn]; }
+    };
+    auto levelA = [&](int k, double &pk, double &tmix, double &qsmix, double &qtmix, double &smix2) {
+        const double tk = t_nx, qk = q_nx, zk = zm_nx + c.zs;
+        pk = pap_nx * 0.01;
         if (k - 1 >= msg + 1) { t_nx = c.t[k - 1]; q_nx = c.q[k - 1]; pap_nx = c.pap[k - 1]; zm_nx = c.zm[k - 1]; }
-        // -- sweep 1: entrain, mix enthalpy, invert for T (:5042-5106)
-        const double dp = (pk - p_kp1);
+        const double dp = (pk - p_kp1);                             // :5042-5106
         const double qtenv = 0.5 * (qk + q_kp1);
         const double tenv = 0.5 * (tk + t_kp1);
         const double penv = 0.5 * (pk + p_kp1);
@@ -321,8 +336,7 @@ __device__ void buoyan_dilute_d(const ZmDev &P, const ColIn &c, double pblt, dou
         qtp = qtp - dmpdp * dp * qtenv;
         mp = mp - dmpdp * dp;
         const double smix1 = (sp0 + sp) / (mp0 + mp);
-        const double qtmix = (qtp0 + qtp) / (mp0 + mp);
-        double tmix, qsmix;
+        qtmix = (qtp0 + qtp) / (mp0 + mp);
         status |= invert_brent<1>(P, smix1, pk, zk, qtmix, tmix, qsmix, tmix1_kp1);
 
         if (qsmix <= qtmix && qsmix1_kp1 > qtmix_kp1) {             // LCL :5111-5133
@@ -340,12 +354,25 @@ __device__ void buoyan_dilute_d(const ZmDev &P, const ColIn &c, double pblt, dou
             status |= invert_brent<1>(P, slcl, pl, zl, qtlcl, r.tl, qslcl, tmix);
         }
         tmix1_kp1 = tmix; qsmix1_kp1 = qsmix; qtmix_kp1 = qtmix; smix1_kp1 = smix1;
+        t_kp1 = tk; q_kp1 = qk; p_kp1 = pk; z_kp1 = zk;
+        smix2 = entropy_d(P, tmix, pk, qtmix);                      // :5204, what sweep 2 starts from
+    };
 
-        // -- sweep 2: rain-out and freezing, two iterations, invert entropy for T (:5202-5267)
-        const double smix2 = entropy_d(P, tmix, pk, qtmix);
+    // ---- sweep 2 (:5175-5273): state and one level ------------------------------------------------------------
+    double xsh2o_kp1 = 0.0, ds_xsh2o_kp1 = 0.0, ds_freeze_kp1 = 0.0, qsmix2_kp1 = 0.0;   // sweep-2 values at k+1
+    auto initB = [&]() {
+        const int k = klaunch;                                      // :5180-5200
+        const double tk = c.T(k), qk = c.Q(k), pk = c.Pm(k);
+        double est;
+        qsat_hPa(P, tk, pk, est, qsmix2_kp1);
+        const double tpk = tk, qstpk = qk;
+        s_tpv[k * WAVE] = (tpk + c.tpert) * (1.0 + qstpk / P.eps1) / (1.0 + qstpk);   // :5194
+        if (STORE_TP && store_ok) { tp[k] = tpk; qstp[k] = qstpk; }
+    };
+    auto levelB = [&](int k, double pk, double tmix, double qsmix, double qtmix, double smix2) {
         double xsh2o = 0.0, ds_xsh2o = 0.0, ds_freeze = 0.0, new_s = 0.0, new_q = 0.0;
 #pragma unroll 1
-        for (int ii = 0; ii < 2; ++ii) {
+        for (int ii = 0; ii < 2; ++ii) {                            // :5202-5267
             xsh2o = fmax(0.0, qtmix - qsmix - lwmax);
             ds_xsh2o = ds_xsh2o_kp1 - P.cpliq * cp_log(tmix / P.tfreez) * fmax(0.0, (xsh2o - xsh2o_kp1));
             if (tmix <= P.tfreez + tscool && ds_freeze_kp1 == 0.0)
@@ -362,18 +389,66 @@ __device__ void buoyan_dilute_d(const ZmDev &P, const ColIn &c, double pblt, dou
         const double tpk = tmix;
         const double qstpk = (new_q > qsmix) ? qsmix : new_q;       // :5249-5253
         s_tpv[k * WAVE] = (tpk + c.tpert) * (1.0 + qstpk / P.eps1) / (1.0 + new_q);     // :5263
-        if (STORE_TP) { tp[k] = tpk; qstp[k] = qstpk; }
+        if (STORE_TP && store_ok) { tp[k] = tpk; qstp[k] = qstpk; }
+    };
 
-        t_kp1 = tk; q_kp1 = qk; p_kp1 = pk; z_kp1 = zk;
+    if (!PIPE) {
+        // one wave does both sweeps of a level back to back (the trigger at ne30 size: 760 blocks already cover three
+        // quarters of the SIMDs, a second wave per block would share SIMDs with other blocks' waves and gain nothing)
+        initA();
+        initB();
+        for (int k = klaunch - 1; k >= msg + 1; --k) {
+            double pk, tmix, qsmix, qtmix, smix2;
+            levelA(k, pk, tmix, qsmix, qtmix, smix2);
+            levelB(k, pk, tmix, qsmix, qtmix, smix2);
+        }
+    } else {
+        // uniform level schedule: at step i wave A works on level pver-1-i, wave B on the level A mailed at step i-1;
+        // levels at or below a lane's launch level are skipped by that lane
+        double *s_fin = s_mail + 2 * MAIL_FIELDS * WAVE + lane;     // [4][WAVE]: lcl, pl, tl, status of wave A
+        const int nsteps = (pver - 1) - (msg + 1) + 2;
+        if (role == 0) {
+            initA();
+            for (int i = 0; i < nsteps; ++i) {
+                const int k = pver - 1 - i;
+                if (k >= msg + 1 && k < klaunch) {
+                    double pk, tmix, qsmix, qtmix, smix2;
+                    levelA(k, pk, tmix, qsmix, qtmix, smix2);
+                    double *m = s_mail + (i & 1) * MAIL_FIELDS * WAVE + lane;
+                    m[0] = tmix; m[WAVE] = qsmix; m[2 * WAVE] = qtmix; m[3 * WAVE] = smix2;
+                }
+                __syncthreads();
+            }
+            s_fin[0] = (double)r.lcl; s_fin[WAVE] = pl; s_fin[2 * WAVE] = r.tl; s_fin[3 * WAVE] = (double)status;
+            __syncthreads();
+            r.status = status;
+            return;
+        }
+        initB();
+        double papb_nx = 0.0;
+        if (klaunch - 1 >= msg + 1) papb_nx = c.pap[klaunch - 1];
+        for (int i = 0; i < nsteps; ++i) {
+            const int k = pver - i;
+            if (i >= 1 && k >= msg + 1 && k < klaunch) {
+                const double pk = papb_nx * 0.01;
+                if (k - 1 >= msg + 1) papb_nx = c.pap[k - 1];
+                const double *m = s_mail + ((i - 1) & 1) * MAIL_FIELDS * WAVE + lane;
+                levelB(k, pk, m[0], m[WAVE], m[2 * WAVE], m[3 * WAVE]);
+            }
+            __syncthreads();
+        }
+        __syncthreads();                                            // wave A's scalars are in s_fin
+        r.lcl = (int)s_fin[0]; pl = s_fin[WAVE]; r.tl = s_fin[2 * WAVE];
+        status |= (int)s_fin[3 * WAVE];
     }
-    if (STORE_TP) {
+    if (STORE_TP && store_ok) {
         for (int k = pver; k > klaunch; --k) { tp[k] = c.T(k); qstp[k] = c.Q(k); }     // :4597-4598
         for (int k = msg; k >= 1; --k) { tp[k] = c.T(k); qstp[k] = c.Q(k); }
     }
 
     // ---- buoyancy, neutral levels, CAPE / CIN (:4742-4816) -----------------------------------------
     const bool plge600 = (pl >= P.plclmin);
-    if (STORE_TP && !plge600) {
+    if (STORE_TP && store_ok && !plge600) {
         for (int k = pver; k >= msg + 1; --k) { tp[k] = c.T(k); qstp[k] = c.Q(k); }     // :4760-4761
     }
     // buoy(k) overwrites tpv(k) in LDS; zero outside [msg+1, mx]
@@ -459,7 +534,7 @@ __global__ __launch_bounds__(WAVE) void zm_trigger_kernel(ZmDev P, int ncol, int
                                                          ZmWorkspace ws)
 {
     CHAIN_PRIO();
-    extern __shared__ double smem[];            // [(pver+2)][WAVE]
+    extern __shared__ double smem[];            // [(pver+2)][WAVE] parcel virtual temperature / buoyancy
     const int col0 = blockIdx.x * WAVE;
     const int nb = min(WAVE, ncol - col0);
     const int lane = threadIdx.x;
@@ -486,7 +561,7 @@ __global__ __launch_bounds__(WAVE) void zm_trigger_kernel(ZmDev P, int ncol, int
     const ColIn c = make_colin(P, io, col, pver);
     const double pblt = pbl_top_index(c);
     BuoyRes r;
-    buoyan_dilute_d<false>(P, c, pblt, -P.tentrm, 0.0, smem + lane, nullptr, nullptr, r);   // :544, 886
+    buoyan_dilute_2w<false, false>(P, c, pblt, -P.tentrm, 0.0, 1, lane, smem + lane, nullptr, nullptr, nullptr, false, r);   // :544, 886
 
     io.cape[col] = r.cape;
     io.status[col] = r.status;
@@ -1035,19 +1110,23 @@ __global__ __launch_bounds__(WAVE) void zm_plume1_kernel(ZmDev P, int ncol, int 
 // ------------------------------------------------------------------------------------------------------
 // Kernel 2b: second dilute ascent of the listed columns with that rate, re-trigger (:1080-1107)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void zm_ascent2_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io, ZmWorkspace ws)
+__global__ __launch_bounds__(2 * WAVE) void zm_ascent2_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io, ZmWorkspace ws)
 {
     CHAIN_PRIO();
-    extern __shared__ double smem[];            // [(pver+2)][WAVE]
-    const int lane = threadIdx.x;
+    extern __shared__ double smem[];            // as zm_trigger_kernel
+    const int lane = threadIdx.x & (WAVE - 1), role = threadIdx.x >> 6;
+    const int count = *ws.count;
+    if ((int)blockIdx.x * WAVE >= count) return;                  // block-uniform
     const int gid = blockIdx.x * WAVE + lane;
-    if (gid >= *ws.count) return;
-    const int col = ws.list[gid];
+    const bool valid = gid < count;
+    const int col = ws.list[valid ? gid : count - 1];             // lanes past the list shadow its last column
     const size_t L = (size_t)pver;
     const ColIn c = make_colin(P, io, col, pver);
     const double pblt = pbl_top_index(c);
     BuoyRes r;
-    buoyan_dilute_d<true>(P, c, pblt, ws.dmpdz2[col], ws.cin1[col], smem + lane, ws.tp2 + col * L - 1, ws.qstp2 + col * L - 1, r);
+    buoyan_dilute_2w<true, true>(P, c, pblt, ws.dmpdz2[col], ws.cin1[col], role, lane, smem + lane, smem + (pver + 2) * WAVE,
+                           ws.tp2 + col * L - 1, ws.qstp2 + col * L - 1, valid, r);
+    if (role == 0 || !valid) return;
     io.cape[col] = r.cape;
     io.status[col] |= r.status;
     ws.cape2[col] = r.cape; ws.tl2[col] = r.tl; ws.lcl2[col] = r.lcl; ws.lel2[col] = r.lel; ws.mx2[col] = r.mx;
@@ -1226,6 +1305,7 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     if (pcols > 1024) return COLPHYS_ERR_ARG;
     const int nblk = (ncol + WAVE - 1) / WAVE;
     const size_t lds = (size_t)(pver + 2) * WAVE * sizeof(double);
+    const size_t lds2 = lds + MAIL_DOUBLES * sizeof(double);       // second ascent: two-wave pipeline with its mailbox
     const int nchunks = (ncol + pcols - 1) / pcols;
     if (hipMemsetAsync(ws.count, 0, sizeof(int), st) != hipSuccess) return COLPHYS_ERR_HIP;
     if (ev) hipEventRecord(ev[0], st);
@@ -1235,7 +1315,7 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     const int nper = ncol < 256 * 12 ? ncol : 256 * 12;       // persistent: ~12 waves per CU fit in LDS at L32
     hipLaunchKernelGGL(zm_plume1_kernel, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, io, ws);
     if (ev) { hipEventRecord(ev[3], st); hipEventRecord(ev[4], st); }
-    hipLaunchKernelGGL(zm_ascent2_kernel, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, io, ws);
+    hipLaunchKernelGGL(zm_ascent2_kernel, dim3(nblk), dim3(2 * WAVE), lds2, st, P, ncol, pver, io, ws);
     if (ev) { hipEventRecord(ev[5], st); hipEventRecord(ev[6], st); }
     hipLaunchKernelGGL(zm_plume2_kernel, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, delt, io, ws);
     hipLaunchKernelGGL(zm_gather_kernel, dim3(nchunks), dim3(WAVE), 0, st, ncol, pver, pcols, io, ws);
