@@ -530,38 +530,53 @@ __device__ __forceinline__ void block_fill(double *p, size_t n, double v)
 // ------------------------------------------------------------------------------------------------------
 // Kernel 1: trigger
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void zm_trigger_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io,
-                                                         ZmWorkspace ws)
+// TRIG_GROUPS column groups of 64 per block, each served by a wave pair (sweep 1 / sweep 2, buoyan_dilute_2w).  The
+// waves are ordered [A0 .. A(G-1), B0 .. B(G-1)] with G = 4: a workgroup's waves are placed on the CU's four SIMDs in a
+// fixed cyclic order, so waves i and i+4 -- the two waves of one column group -- share a SIMD.  That is the point: at
+// ne30 size there are only 760 column groups for 1 024 SIMDs, a second wave per group on ANOTHER SIMD would just
+// collide with other groups' waves, while on the SAME SIMD the pair fills each other's dependent-issue bubbles (a single
+// ascent wave keeps its SIMD 62 % busy) and the per-level latency drops to the longer sweep's.
+// (G < 4 when the per-group LDS does not allow four groups, e.g. L70: the pairs then sit on different SIMDs.)
+#ifndef TRIG_GROUPS_MAX
+#define TRIG_GROUPS_MAX 4
+#endif
+__global__ __launch_bounds__(2 * TRIG_GROUPS_MAX * WAVE) void zm_trigger_kernel(ZmDev P, int ncol, int pver, int TRIG_GROUPS,
+                                                                               colphys_zm_convr_io io, ZmWorkspace ws)
 {
     CHAIN_PRIO();
-    extern __shared__ double smem[];            // [(pver+2)][WAVE] parcel virtual temperature / buoyancy
-    const int col0 = blockIdx.x * WAVE;
-    const int nb = min(WAVE, ncol - col0);
-    const int lane = threadIdx.x;
-    const int col = col0 + lane;
+    extern __shared__ double smem[];            // per group: [(pver+2)][WAVE] parcel virtual temperature / buoyancy + mailbox
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+    const int role = wave / TRIG_GROUPS, group = wave % TRIG_GROUPS;
+    const int bcol0 = blockIdx.x * TRIG_GROUPS * WAVE;
+    const int bnb = min(TRIG_GROUPS * WAVE, ncol - bcol0);          // columns of this block
+    const int col = bcol0 + group * WAVE + lane;
+    const bool valid = col < ncol;
     const size_t L = (size_t)pver, LP = (size_t)pver + 1;
+    double *gmem = smem + (size_t)group * ((pver + 2) * WAVE + MAIL_DOUBLES);
 
     // zero-fill every output of this block's columns, coalesced (:559-563, 625-650, 771-784 and the
     // gathered arrays, whose slots beyond lengath the reference leaves stale)
     {
         double *mid[] = {io.qtnd, io.heat, io.cme, io.zdu, io.rprd, io.dlf, io.ql, io.dif, io.dnlf, io.dnif, io.eurt,
                          io.mu, io.md, io.du, io.eu, io.ed, io.dp};
-        for (double *p : mid) block_fill(p + col0 * L, nb * L, 0.0);
-        block_fill(io.mcon + col0 * LP, nb * LP, 0.0);
-        block_fill(io.pflx + col0 * LP, nb * LP, 0.0);
+        for (double *p : mid) block_fill(p + bcol0 * L, bnb * L, 0.0);
+        block_fill(io.mcon + bcol0 * LP, bnb * LP, 0.0);
+        block_fill(io.pflx + bcol0 * LP, bnb * LP, 0.0);
     }
-    if (lane < nb) {
+    if (role == 1 && valid) {
         io.prec[col] = 0.0; io.rliq[col] = 0.0; io.rice[col] = 0.0;
         io.jctop[col] = pver; io.jcbot[col] = 1;
         io.dsubcld[col] = 0.0; io.jt[col] = 0; io.maxg[col] = 0; io.ideep[col] = 0;
         ws.deep[col] = 0;
     }
-    if (lane >= nb) return;
 
-    const ColIn c = make_colin(P, io, col, pver);
+    // lanes past the last column shadow it (the pipeline's barriers need every lane); nothing of theirs is stored
+    const ColIn c = make_colin(P, io, valid ? col : ncol - 1, pver);
     const double pblt = pbl_top_index(c);
     BuoyRes r;
-    buoyan_dilute_2w<false, false>(P, c, pblt, -P.tentrm, 0.0, 1, lane, smem + lane, nullptr, nullptr, nullptr, false, r);   // :544, 886
+    buoyan_dilute_2w<false, true>(P, c, pblt, -P.tentrm, 0.0, role, lane, gmem + lane, gmem + (pver + 2) * WAVE, nullptr,
+                                  nullptr, false, r);                                             // :544, 886
+    if (role == 0 || !valid) return;
 
     io.cape[col] = r.cape;
     io.status[col] = r.status;
@@ -1309,7 +1324,13 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     const int nchunks = (ncol + pcols - 1) / pcols;
     if (hipMemsetAsync(ws.count, 0, sizeof(int), st) != hipSuccess) return COLPHYS_ERR_HIP;
     if (ev) hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL(zm_trigger_kernel, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, io, ws);
+    int groups = TRIG_GROUPS_MAX;                              // column groups (wave pairs) per trigger block
+    while (groups > 1 && lds2 * groups > 150 * 1024) groups /= 2;
+    const int ntrig = (ncol + groups * WAVE - 1) / (groups * WAVE);
+    const size_t ldst = lds2 * groups;
+    if (ldst > 160 * 1024) return COLPHYS_ERR_UNSUPPORTED;
+    if (ldst > 64 * 1024) hipFuncSetAttribute((const void *)zm_trigger_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);
+    hipLaunchKernelGGL(zm_trigger_kernel, dim3(ntrig), dim3(2 * groups * WAVE), ldst, st, P, ncol, pver, groups, io, ws);
     if (ev) { hipEventRecord(ev[1], st); hipEventRecord(ev[2], st); }
     const size_t lds_w = (size_t)(PLUME_NARR + 2) * (pver + 2) * sizeof(double);
     const int nper = ncol < 256 * 12 ? ncol : 256 * 12;       // persistent: ~12 waves per CU fit in LDS at L32
