@@ -482,6 +482,10 @@ int colphys_aero_tables_set(const colphys_aero_tables *tb)
             e[m] = std::exp(2.0 * alnsg * alnsg);
         }
         bad |= up(e.data(), 8 * nm, (const void **)&A.explnsigma);
+        std::vector<double> rd(nm * ns);
+        for (size_t i = 0; i < nm * ns; ++i) rd[i] = 1.0 / tb->specdens[i];
+        bad |= up(rd.data(), 8 * nm * ns, (const void **)&A.rspecdens);
+        A.rxrange = 1.0 / (tb->xrmax - tb->xrmin);
     }
     if (bad) return fail(COLPHYS_ERR_HIP, "uploading packed aerosol table slices failed");
     g_aero_set = true;

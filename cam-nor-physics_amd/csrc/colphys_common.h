@@ -50,6 +50,8 @@ struct AeroDev {
     // interval widths rdxr[PREFR], rdxi[PREFI] (0 where the interval is degenerate and for the last point), zero fill to 1 KiB
     const double *slices_sw, *slices_lw;
     const double *explnsigma;       // [nmodes] exp(2 ln(sigmag)^2), modal_aer_opt.F90:1553-1554
+    const double *rspecdens;        // [nmodes][nspec_max] 1/specdens
+    double rxrange;                 // 1/(xrmax - xrmin)
 };
 constexpr int AERO_NCP = 6;
 constexpr int AERO_TBLP = COLPHYS_PREFI * COLPHYS_PREFR * AERO_NCP;

@@ -113,7 +113,7 @@ __device__ __forceinline__ void size_parameters(const AeroDev &A, double explnsi
     logradsurf = cp_log(radsurf);
     double xrad = fmax(logradsurf, A.xrmin);
     xrad = fmin(xrad, A.xrmax);
-    xrad = (2.0 * xrad - A.xrmax - A.xrmin) / (A.xrmax - A.xrmin);
+    xrad = (2.0 * xrad - A.xrmax - A.xrmin) * A.rxrange;           // /(xrmax - xrmin), :1563, as a product
     cheb[0] = 1.0;
     cheb[1] = xrad;
 #pragma unroll
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
 #pragma unroll
         for (int l = 0; l < NSMAX; ++l) {                               // :764-766
             if (l < nspec) {
-                vol[l] = vol[l] / as_const(A.specdens)[m * A.nspec_max + l];
+                vol[l] = vol[l] * as_const(A.rspecdens)[m * A.nspec_max + l];     // specmmr/specdens (:765) as a product
                 dryvol = dryvol + vol[l];
             }
         }
@@ -194,7 +194,6 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
         double wetvol = watervol + dryvol;
         if (watervol < 0.0) { watervol = 0.0; wetvol = dryvol; }
         const bool small = logradsurf <= A.xrmax;
-        const double pext_large = 1.5 / (radsurf * A.rhoh2o);           // :875
         // cre/wetvol, cim/wetvol (:850 / :1377) as products with one reciprocal per (cell, mode): last-bit difference
         const double wetinv = 1.0 / (SW ? fmax(wetvol, 1.e-60) : wetvol);
 
@@ -243,7 +242,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
                 double pabs = interp_cheb(s_tbl + TBLP, wr, wi, cheb);  // :861, 882-887
                 const double pasm = interp_cheb(s_tbl + 2 * TBLP, wr, wi, cheb);   // :862
                 const double pe = exp(pext);                            // :869-877
-                pext = small ? pe : pext_large;
+                pext = small ? pe : 1.5 / (radsurf * A.rhoh2o);         // :875 (particles beyond the table: rare)
                 pext = pext * wetvol * A.rhoh2o;                        // :881-894
                 pabs = pabs * wetvol * A.rhoh2o;
                 pabs = fmax(0.0, pabs);
