@@ -300,6 +300,50 @@ def test_chunk_entry_points_match_device_entry_points():
             assert np.array_equal(hout[k][c, 0, :lg], o[k][:lg]), k
 
 
+@pytest.mark.parametrize("ncol", [1, 5, 63, 64, 65, 257, 300])
+def test_ragged_column_counts_vs_c_oracle(ncol):
+    """block tails of every kernel on the path: partial waves, partial column groups of the trigger's wave pairs, a
+    partial last chunk, and the column-count-one case"""
+    from c_oracle import COracle
+    pver = 32
+    params = cases.default_params(pver)
+    eng = engine(params)
+    co = COracle(params)
+    st = synth.make_state(ncol, pver, 77 + ncol, rh_range=(0.75, 0.98))          # moist: most columns convect
+    c = synth.PHYSCONST
+    d = eng.dev
+    ga = cases.geo_args(st)
+    zi_r, zm_r = co.geopotential_t(*ga, st["q"], st["rair"], c["gravit"], st["zvir"], dycore=abi.DYCORE_FV)
+    zi, zm = eng.geopotential_t(*[d(x) for x in ga], d(st["q"]), d(st["rair"]), c["gravit"], d(st["zvir"]))
+    assert_close("geopotential_t.zi", zi.cpu().numpy(), zi_r)
+    args = cases.zm_args_from_state(st, zi_r, zm_r)
+    ref = co.zm_convr(*args)
+    o = run_zm(eng, args)
+    check_zm(o, ref, ncol)
+    dt = synth.ZTODT
+    ea = (st["t"], st["pmid"], st["pdel"], st["q"], st["landfrac"], ref["rprd"], st["cld"], dt, ref["prec"])
+    e_ref = co.zm_conv_evap(*ea)
+    e = to_np(eng.zm_conv_evap(*[d(x) for x in ea[:7]], dt, d(ref["prec"].copy())))
+    for k, v in e.items():
+        assert_close("zm_conv_evap." + k, v, e_ref[k])
+    m_ref = co.momtran(st["u"], st["v"], ref["mu"], ref["md"], ref["du"], ref["eu"], ref["ed"], ref["dp"], ref["dsubcld"],
+                       ref["jt"], ref["maxg"], ref["ideep"], ref["lengath"], dt)
+    m = to_np(eng.momtran(d(np.stack([st["u"], st["v"]])), *[d(ref[k]) for k in ("mu", "md", "du", "eu", "ed", "dp", "dsubcld")],
+                          *[d(ref[k]) for k in ("jt", "maxg", "ideep", "lengath")], dt))
+    for k, v in m.items():
+        assert_close("momtran." + k, v, m_ref[k])
+    props = synth.make_aero_props(3)
+    aer = synth.make_aero_state(ncol, pver, props, 3)
+    eng.aero_tables_set(props, c)
+    co.aero_tables_set(props, c)
+    a = (d(st["pdeldry"]), d(aer["specmmr"]), d(aer["dgnumwet"]), d(aer["qaerwat"]))
+    sw, sw_ref = to_np(eng.modal_aero_sw(*a)), co.modal_aero_sw(st, aer)
+    lw, lw_ref = to_np(eng.modal_aero_lw(*a)), co.modal_aero_lw(st, aer)
+    for k in ("tauxar", "wa", "ga", "fa"):
+        assert_close("modal_aero_sw." + k, sw[k], sw_ref[k])
+    assert_close("modal_aero_lw.tauxar", lw["tauxar"], lw_ref["tauxar"])
+
+
 # ---------------------------------------------------------------------------------------------------
 # (d) the device logarithms that stand where the reference calls its libm
 # ---------------------------------------------------------------------------------------------------
