@@ -2,10 +2,13 @@
 // host-layout (chunk) entry points the ISO_C_BINDING shim calls.  No CPU fallback anywhere: without a HIP
 // device every compute entry point returns COLPHYS_ERR_NODEVICE.
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "colphys_common.h"
@@ -517,44 +520,113 @@ int colphys_modal_aero_lw_dev(int ncol, int pver, const colphys_modal_aero_io *i
 
 namespace {
 
+// ---- host worker pool for the layout transposes of the chunk entry points -------------------------------------
+// (pcols, nlev, nchunks) <-> [col][nlev] is a strided copy of every field of a rank (~0.3 GB per zm_convr call at ne30):
+// one core moves it at ~10 GB/s, less than PCIe, so the chunk range is split over a few persistent threads.
+class HostPool {
+public:
+    static HostPool &get() { static HostPool p; return p; }
+    // f(lo, hi) over [0, n) in contiguous pieces; runs inline when the range is small
+    void run(int n, const std::function<void(int, int)> &f)
+    {
+        const int T = (int)workers_.size() + 1;
+        if (T == 1 || n < 64 * T) { f(0, n); return; }
+        const int per = (n + T - 1) / T;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &f; n_ = n; per_ = per; pending_ = T - 1; ++gen_;
+        }
+        cv_.notify_all();
+        f(0, per < n ? per : n);                       // the caller takes the first piece
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+    ~HostPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+private:
+    HostPool()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        int T = hw ? (int)hw : 1;
+        if (const char *e = getenv("COLPHYS_HOST_THREADS")) T = atoi(e);
+        T = T < 1 ? 1 : (T > 8 ? 8 : T);               // memory-bound: a few threads saturate the copy
+        for (int i = 1; i < T; ++i) workers_.emplace_back([this, i] { loop(i); });
+    }
+    void loop(int id)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int, int)> *f;
+            int lo, hi;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                f = fn_; lo = id * per_; hi = lo + per_ < n_ ? lo + per_ : n_;
+            }
+            if (f && lo < hi) (*f)(lo, hi);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int, int)> *fn_ = nullptr;
+    int n_ = 0, per_ = 0, pending_ = 0;
+    unsigned long gen_ = 0;
+    bool stop_ = false;
+};
+
 struct Stager {
     int nchunks, pcols;
     const int32_t *ncol;
     int ncd;                       // device columns = nchunks*pcols
     Carver hc, dc;
     hipStream_t st = nullptr;
+    hipEvent_t ev_pending = nullptr;
+    std::function<void()> scatter_pending;     // scatter of the previous download, run while the next one is in flight
     Stager(int nch, int pc, const int32_t *nc, void *hbase, void *dbase) : nchunks(nch), pcols(pc), ncol(nc), ncd(nch * pc), hc(hbase), dc(dbase) {}
+    ~Stager()
+    {
+        drain();
+        if (ev_pending) hipEventDestroy(ev_pending);
+    }
+    void drain()
+    {
+        if (scatter_pending) {
+            hipEventSynchronize(ev_pending);
+            scatter_pending();
+            scatter_pending = nullptr;
+        }
+    }
 
     // pack a (pcols, nlev, nchunks) Fortran field and start its upload; returns the device pointer
-    double *in(const double *src, int nlev)
-    {
-        const size_t n = (size_t)ncd * nlev;
-        double *h = hc.take<double>(n), *d = dc.take<double>(n);
-        for (int c = 0; c < nchunks; ++c) {
-            const double *s = src + (size_t)c * pcols * nlev;
-            for (int i = 0; i < pcols; ++i) {
-                const int isrc = (i < ncol[c]) ? i : 0;
-                double *o = h + ((size_t)c * pcols + i) * nlev;
-                for (int k = 0; k < nlev; ++k) o[k] = s[(size_t)k * pcols + isrc];
-            }
-        }
-        hipMemcpyAsync(d, h, n * sizeof(double), hipMemcpyHostToDevice, st);
-        return d;
-    }
+    double *in(const double *src, int nlev) { return in_multi(src, nlev, 1); }
     // nf fields, source field-major (pcols, nlev, nchunks, nf) -> device [nf][ncd][nlev], contiguous
     double *in_multi(const double *src, int nlev, int nf)
     {
         const size_t n = (size_t)ncd * nlev;
         double *h = hc.take<double>(n * nf), *d = dc.take<double>(n * nf);
-        for (int f = 0; f < nf; ++f)
-            for (int c = 0; c < nchunks; ++c) {
-                const double *s = src + (size_t)f * n + (size_t)c * pcols * nlev;
-                for (int i = 0; i < pcols; ++i) {
-                    const int isrc = (i < ncol[c]) ? i : 0;
-                    double *o = h + (size_t)f * n + ((size_t)c * pcols + i) * nlev;
-                    for (int k = 0; k < nlev; ++k) o[k] = s[(size_t)k * pcols + isrc];
+        HostPool::get().run(nchunks, [&](int c0, int c1) {
+            for (int f = 0; f < nf; ++f)
+                for (int c = c0; c < c1; ++c) {
+                    const double *s = src + (size_t)f * n + (size_t)c * pcols * nlev;
+                    for (int i = 0; i < pcols; ++i) {
+                        const int isrc = (i < ncol[c]) ? i : 0;
+                        double *o = h + (size_t)f * n + ((size_t)c * pcols + i) * nlev;
+                        for (int k = 0; k < nlev; ++k) o[k] = s[(size_t)k * pcols + isrc];
+                    }
                 }
-            }
+        });
         hipMemcpyAsync(d, h, n * nf * sizeof(double), hipMemcpyHostToDevice, st);
         return d;
     }
@@ -562,29 +634,39 @@ struct Stager {
     {
         const size_t n = (size_t)ncd * nlev;
         int32_t *h = hc.take<int32_t>(n), *d = dc.take<int32_t>(n);
-        for (int c = 0; c < nchunks; ++c)
-            for (int i = 0; i < pcols; ++i)
-                for (int k = 0; k < nlev; ++k) h[((size_t)c * pcols + i) * nlev + k] = src[(size_t)c * pcols * nlev + (size_t)k * pcols + i];
+        HostPool::get().run(nchunks, [&](int c0, int c1) {
+            for (int c = c0; c < c1; ++c)
+                for (int i = 0; i < pcols; ++i)
+                    for (int k = 0; k < nlev; ++k) h[((size_t)c * pcols + i) * nlev + k] = src[(size_t)c * pcols * nlev + (size_t)k * pcols + i];
+        });
         hipMemcpyAsync(d, h, n * sizeof(int32_t), hipMemcpyHostToDevice, st);
         return d;
     }
     template <class T> T *out(int nlev) { return dc.take<T>((size_t)ncd * nlev); }
 
-    // download a device [col][nlev] field and scatter the first `valid(c)` columns of each chunk
+    // download a device [col][nlev] field and scatter the first `valid(c)` columns of each chunk; the scatter of one
+    // field runs while the download of the next is in flight (the last one is drained by the destructor)
     template <class T> void back(T *dst, const T *dev, int nlev, bool gathered, const int32_t *lengath)
     {
         const size_t n = (size_t)ncd * nlev;
         T *h = hc.take<T>(n);
         hipMemcpyAsync(h, dev, n * sizeof(T), hipMemcpyDeviceToHost, st);
-        hipStreamSynchronize(st);
-        for (int c = 0; c < nchunks; ++c) {
-            const int nv = gathered ? lengath[c] : ncol[c];
-            T *o = dst + (size_t)c * pcols * nlev;
-            for (int i = 0; i < nv; ++i) {
-                const T *s = h + ((size_t)c * pcols + i) * nlev;
-                for (int k = 0; k < nlev; ++k) o[(size_t)k * pcols + i] = s[k];
-            }
-        }
+        drain();                                       // previous field: wait for ITS copy, scatter it
+        if (!ev_pending) hipEventCreateWithFlags(&ev_pending, hipEventDisableTiming);
+        hipEventRecord(ev_pending, st);
+        Stager *self = this;
+        scatter_pending = [self, dst, h, nlev, gathered, lengath]() {
+            HostPool::get().run(self->nchunks, [&](int c0, int c1) {
+                for (int c = c0; c < c1; ++c) {
+                    const int nv = gathered ? lengath[c] : self->ncol[c];
+                    T *o = dst + (size_t)c * self->pcols * nlev;
+                    for (int i = 0; i < nv; ++i) {
+                        const T *s = h + ((size_t)c * self->pcols + i) * nlev;
+                        for (int k = 0; k < nlev; ++k) o[(size_t)k * self->pcols + i] = s[k];
+                    }
+                }
+            });
+        };
     }
 };
 
