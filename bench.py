@@ -143,17 +143,8 @@ def main():
     # ---- resident inputs (physics_state of this rank's columns) and pre-allocated outputs -----------------
     S = {k: d(st[k]) for k in ("t", "q", "u", "v", "pint", "pmid", "pdel", "rpdel", "lnpint", "lnpmid", "pdeldry", "phis",
                                "pblh", "tpert", "landfrac", "cld", "rair", "zvir", "zi", "zm")}
-    winds0 = torch.stack([S["u"], S["v"]]).contiguous()
-    zm_out = eng.alloc_zm_convr_out(ncol, pver, pcols)
-    t1, q1 = eng.empty(ncol, pver), eng.empty(ncol, pver)
-    winds1 = eng.empty(2, ncol, pver)
-    zi1, zm1 = eng.empty(ncol, pver + 1), eng.empty(ncol, pver)
-    prec1 = eng.empty(ncol)
-    ev_out = {k: eng.empty(ncol, pver) for k in abi.EVAP_OUT_MID}
-    ev_out.update({k: eng.empty(ncol, pver + 1) for k in abi.EVAP_OUT_INT})
-    ev_out["snow"] = eng.empty(ncol)
-    mom_out = {k: eng.empty(2, ncol, pver) for k in abi.MOMTRAN_OUT_3D}
-    mom_out["seten"] = eng.empty(ncol, pver)
+    S["ps"] = d(st["pint"][:, -1].copy())
+    zm_out = eng.alloc_zm_conv_tend_out(ncol, pver, pcols)
     if with_aero:
         eng.aero_tables_set(props, c)
         A = {k: d(aer[k]) for k in ("specmmr", "dgnumwet", "qaerwat")}
@@ -161,12 +152,8 @@ def main():
         sw_out["status"] = eng.empty(ncol, dtype=torch.int32)
         lw_out = dict(tauxar=eng.empty(ncol, synth.NLWBANDS, pver), status=eng.empty(ncol, dtype=torch.int32))
 
-    def geo(t, q):
-        eng.geopotential_t(S["lnpint"], S["lnpmid"], S["pint"], S["pmid"], S["pdel"], S["rpdel"], t, q, S["rair"],
-                           c["gravit"], S["zvir"], zi=zi1, zm=zm1)
-
     # The optics kernels share no data with the ZM chain, so they go on a second HIP stream and fill the SIMDs
-    # the latency-bound ZM kernels leave idle (760 waves, then ~80, on 1 024 SIMDs); --serial disables it.
+    # the latency-bound ZM kernels leave idle (760 column groups, then ~80, on 1 024 SIMDs); --serial disables it.
     side = torch.cuda.Stream(priority=0) if (with_aero and not args.serial) else None
 
     def aero():
@@ -178,28 +165,15 @@ def main():
     def substep():
         if side is not None:
             step_start.record()
-        # zm_conv_tend, zm_conv_intr.F90:662-836
-        eng.zm_convr(S["t"], S["q"], S["pblh"], S["zm"], S["phis"], S["zi"], S["pmid"], S["pint"], S["pdel"], 0.5 * dt,
-                     S["tpert"], S["landfrac"], pcols=pcols, out=zm_out)
+        # zm_conv_tend (zm_conv_intr.F90:441-905) on resident data, ONE call of the C ABI: zm_convr -> physics_update ->
+        # geopotential_t -> zm_conv_evap -> physics_update -> geopotential_t -> momtran -> physics_update -> geopotential_t,
+        # ptend_all and the diagnostics accumulated on the device.  The engine enqueues the trigger first; the optics are
+        # enqueued right behind it on the side stream so that its long-running waves are placed before the optics' blocks.
+        eng.zm_conv_tend(S, dt, pcols=pcols, out=zm_out)
         if side is not None:
-            # enqueued AFTER the trigger kernel so its 760 long-running waves are placed first (one per SIMD);
-            # the optics blocks then fill the register / LDS space that is left
             side.wait_event(step_start)
             with torch.cuda.stream(side):
                 aero()
-        eng.physics_update(dt, c["cpair"], t=(S["t"], zm_out["heat"], t1), q=(S["q"], zm_out["qtnd"], q1))       # :739
-        geo(t1, q1)
-        prec1.copy_(zm_out["prec"])
-        eng.zm_conv_evap(t1, S["pmid"], S["pdel"], q1, S["landfrac"], zm_out["rprd"], S["cld"], dt, prec1, out=ev_out)
-        eng.physics_update(dt, c["cpair"], t=(t1, ev_out["tend_s"], t1), q=(q1, ev_out["tend_q"], q1))            # :806
-        geo(t1, q1)
-        eng.momtran(winds0, zm_out["mu"], zm_out["md"], zm_out["du"], zm_out["eu"], zm_out["ed"], zm_out["dp"],
-                    zm_out["dsubcld"], zm_out["jt"], zm_out["maxg"], zm_out["ideep"], zm_out["lengath"], dt, pcols=pcols,
-                    out=mom_out)
-        eng.physics_update(dt, c["cpair"], t=(t1, mom_out["seten"], t1), u=(winds0[0], mom_out["dqdt"][0], winds1[0]),
-                           v=(winds0[1], mom_out["dqdt"][1], winds1[1]))                                            # :836
-        geo(t1, q1)
-        if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         elif with_aero:
             aero()
@@ -246,7 +220,7 @@ def main():
     if graph is not None:
         def fingerprint():
             torch.cuda.synchronize()
-            parts = [zm_out["heat"].sum(), zm_out["prec"].sum(), ev_out["tend_q"].sum(), mom_out["seten"].sum(), zm1.sum()]
+            parts = [zm_out["ptend_s"].sum(), zm_out["prec"].sum(), zm_out["evapcdp"].sum(), zm_out["ptend_u"].sum(), zm_out["zm1"].sum()]
             if with_aero:
                 parts += [sw_out["tauxar"].sum(), lw_out["tauxar"].sum()]
             return torch.stack(parts).cpu()

@@ -106,6 +106,32 @@ class ConvtranIO(C.Structure):
     )
 
 
+# zm_conv_tend on resident data (colphys_zm_conv_tend_io): name -> (kind, levels); kind "d" double, "i" int32; levels 0 = [ncol],
+# 1 = [ncol][pver], 2 = [ncol][pver+1], 3 = [nchunks]
+ZM_TEND_IN = ("t", "q", "u", "v", "pmid", "pint", "pdel", "rpdel", "lnpint", "lnpmid", "zm", "zi", "phis", "ps", "rair", "zvir",
+              "pblh", "tpert", "landfrac", "cld")
+ZM_TEND_OUT = {
+    "ptend_s": 1, "ptend_q": 1, "ptend_u": 1, "ptend_v": 1,
+    "prec": 0, "snow": 0, "rliq": 0, "rice": 0, "jctop": 0, "jcbot": 0, "cape": 0,
+    "ql": 1, "rprd": 1, "evapcdp": 1, "dlf": 1, "mconzm": 2, "flxprec": 2, "flxsnow": 2,
+    "mu": 1, "md": 1, "du": 1, "eu": 1, "ed": 1, "dp": 1, "dsubcld": 0,
+}
+ZM_TEND_OUT_I = {"jt": 0, "maxg": 0, "ideep": 0, "lengath": 3}
+ZM_TEND_DIAG = {"freqzm": 0, "pcont": 0, "pconb": 0, "mu_out": 1, "md_out": 1}
+ZM_TEND_STATE1 = {"t1": 1, "q1": 1, "u1": 1, "v1": 1, "zi1": 2, "zm1": 1}
+
+
+class ZmConvTendIO(C.Structure):
+    _fields_ = (
+        [(n, PD) for n in ZM_TEND_IN]
+        + [(n, PD) for n in ZM_TEND_OUT]
+        + [(n, PI) for n in ZM_TEND_OUT_I]
+        + [(n, PD) for n in ZM_TEND_DIAG]
+        + [(n, PD) for n in ZM_TEND_STATE1]
+        + [("status", PI)]
+    )
+
+
 class AeroTables(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ("nmodes", "nspec_max", "nswbands", "nlwbands", "top_lev",

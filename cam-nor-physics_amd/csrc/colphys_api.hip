@@ -60,6 +60,7 @@ struct Arena {
 Arena g_ws_arena;        // ZmWorkspace
 Arena g_dev_arena;       // device staging for *_chunks
 Arena g_pin_arena;       // pinned host staging for *_chunks
+Arena g_tend_arena;      // work arrays of colphys_zm_conv_tend_dev
 
 // carve helper
 struct Carver {
@@ -249,7 +250,7 @@ int colphys_finalize(void)
         for (void *b : g_aero_bufs) hipFree(b);
         g_aero_bufs.clear();
         g_aero_set = false;
-        g_ws_arena.release(); g_dev_arena.release(); g_pin_arena.release();
+        g_ws_arena.release(); g_dev_arena.release(); g_pin_arena.release(); g_tend_arena.release();
     }
     g_init = false;
     return COLPHYS_OK;
@@ -392,6 +393,101 @@ int colphys_physics_update_dev(int ncol, int pver, double dt, double cpair, doub
     rc = launch_physics_update(ncol, pver, dt, cpair, qmin, t_in, s_tend, t_out, q_in, q_tend, q_out, u_in, u_tend, u_out,
                                v_in, v_tend, v_out, (hipStream_t)stream);
     return rc ? fail(rc, "physics_update launch failed") : COLPHYS_OK;
+}
+
+// ---- zm_conv_tend on resident data (zm_conv_intr.F90:441-905) ---------------------------------------------------
+int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dycore_kind, double qmin,
+                             const colphys_zm_conv_tend_io *io, void *stream)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    if (!io) return fail(COLPHYS_ERR_ARG, "null io");
+    if (pcols < 1 || pcols > 1024) return fail(COLPHYS_ERR_ARG, "pcols must be in 1..1024");
+    {
+        const void *need[] = {io->t, io->q, io->u, io->v, io->pmid, io->pint, io->pdel, io->rpdel, io->lnpint, io->lnpmid, io->zm,
+                              io->zi, io->phis, io->ps, io->rair, io->zvir, io->pblh, io->tpert, io->landfrac, io->cld,
+                              io->ptend_s, io->ptend_q, io->ptend_u, io->ptend_v, io->prec, io->snow, io->rliq, io->rice,
+                              io->jctop, io->jcbot, io->cape, io->ql, io->rprd, io->evapcdp, io->dlf, io->mconzm, io->flxprec,
+                              io->flxsnow, io->mu, io->md, io->du, io->eu, io->ed, io->dp, io->dsubcld, io->jt, io->maxg,
+                              io->ideep, io->lengath, io->status};
+        for (const void *p : need)
+            if (!p) return fail(COLPHYS_ERR_ARG, "null pointer in colphys_zm_conv_tend_io");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nM = (size_t)ncol * pver, nI = (size_t)ncol * (pver + 1);
+
+    // work arrays: ptend_loc of the three stages, what zm_conv_tend only hands to outfld, and state1
+    std::unique_lock<std::mutex> lk(g_mu);
+    const size_t bytes = 8 * (30 * nM + 3 * nI + 8 * (size_t)ncol) + 64 * 256;
+    if (g_tend_arena.reserve(bytes)) return fail(COLPHYS_ERR_HIP, "work-array allocation failed");
+    Carver w(g_tend_arena.p);
+    lk.unlock();
+    double *heat = w.take<double>(nM), *qtnd = w.take<double>(nM), *cme = w.take<double>(nM), *zdu = w.take<double>(nM),
+           *dif = w.take<double>(nM), *dnlf = w.take<double>(nM), *dnif = w.take<double>(nM), *eurt = w.take<double>(nM),
+           *mcon = w.take<double>(nI), *pflx = w.take<double>(nI);
+    double *tend_s = w.take<double>(nM), *snwprd = w.take<double>(nM), *snwevmlt = w.take<double>(nM), *tend_q = io->evapcdp,
+           *ntprprd = w.take<double>(nM), *ntsnprd = w.take<double>(nM);
+    double *winds = w.take<double>(2 * nM), *wtend = w.take<double>(2 * nM), *pguall = w.take<double>(2 * nM),
+           *pgdall = w.take<double>(2 * nM), *icwu = w.take<double>(2 * nM), *icwd = w.take<double>(2 * nM),
+           *seten = w.take<double>(nM);
+    double *t1 = io->t1 ? io->t1 : w.take<double>(nM), *q1 = io->q1 ? io->q1 : w.take<double>(nM);
+    double *u1 = io->u1 ? io->u1 : w.take<double>(nM), *v1 = io->v1 ? io->v1 : w.take<double>(nM);
+    double *zi1 = io->zi1 ? io->zi1 : w.take<double>(nI), *zm1 = io->zm1 ? io->zm1 : w.take<double>(nM);
+
+    // ---- zm_convr on the incoming state, delt = ztodt/2 (:662-675) ------------------------------------------
+    colphys_zm_convr_io c{};
+    c.t = io->t; c.qh = io->q; c.pap = io->pmid; c.dpp = io->pdel; c.zm = io->zm; c.paph = io->pint; c.zi = io->zi;
+    c.geos = io->phis; c.pblh = io->pblh; c.tpert = io->tpert; c.landfrac = io->landfrac;
+    c.qtnd = qtnd; c.heat = heat; c.cme = cme; c.zdu = zdu; c.rprd = io->rprd; c.dlf = io->dlf; c.ql = io->ql; c.dif = dif;
+    c.dnlf = dnlf; c.dnif = dnif; c.eurt = eurt; c.mcon = mcon; c.pflx = pflx;
+    c.prec = io->prec; c.jctop = io->jctop; c.jcbot = io->jcbot; c.cape = io->cape; c.rliq = io->rliq; c.rice = io->rice;
+    c.mu = io->mu; c.md = io->md; c.du = io->du; c.eu = io->eu; c.ed = io->ed; c.dp = io->dp; c.dsubcld = io->dsubcld;
+    c.jt = io->jt; c.maxg = io->maxg; c.ideep = io->ideep; c.lengath = io->lengath; c.status = io->status;
+    if ((rc = colphys_zm_convr_dev(ncol, pver, pcols, 0.5 * ztodt, &c, stream))) return rc;
+
+    // ---- mass flux units and the gathered diagnostics (:685-731) --------------------------------------------
+    if ((rc = launch_zm_tend_diag(ncol, pver, pcols, g_P.gravit, mcon, io->mconzm, io->ps, io->pmid, io->mu, io->md, io->jt,
+                                  io->maxg, io->ideep, io->lengath, io->freqzm, io->pcont, io->pconb, io->mu_out, io->md_out, st)))
+        return fail(rc, "zm_conv_tend diagnostics launch failed");
+
+    auto update = [&](const double *ti, const double *s, const double *qi, const double *qt, const double *ui, const double *ut,
+                      const double *vi, const double *vt, int first) -> int {
+        // physics_ptend_sum + physics_update (tendency application) + geopotential_t, physics_types.F90:292-340, 425-441
+        ProfScope ps(COLPHYS_K_UPDATE, st);
+        int r = launch_physics_update(ncol, pver, ztodt, g_P.cpair, qmin, ti, s, t1, qi, qt, qt ? q1 : nullptr, ui, ut,
+                                      ut ? u1 : nullptr, vi, vt, vt ? v1 : nullptr, st, io->ptend_s, io->ptend_q, io->ptend_u,
+                                      io->ptend_v, first);
+        return r;
+    };
+    auto geopotential = [&]() -> int {
+        return colphys_geopotential_t_dev(ncol, pver, dycore_kind, 1, 1, io->lnpint, io->lnpmid, io->pint, io->pmid, io->pdel,
+                                          io->rpdel, t1, q1, io->rair, g_P.gravit, io->zvir, zi1, zm1, stream);
+    };
+
+    // ---- ptend_all = ptend_loc; state1 = state + ptend_loc dt (:737-739) -----------------------------------
+    if ((rc = update(io->t, heat, io->q, qtnd, nullptr, nullptr, nullptr, nullptr, 1 | 2))) return fail(rc, "physics_update launch failed");
+    if ((rc = geopotential())) return rc;
+
+    // ---- zm_conv_evap on state1 (:764-771); evapcdp = its dq/dt (:773) ----------------------------------------
+    colphys_zm_conv_evap_io e{};
+    e.t = t1; e.pmid = io->pmid; e.pdel = io->pdel; e.q = q1; e.prdprec = io->rprd; e.cldfrc = io->cld; e.landfrac = io->landfrac;
+    e.prec = io->prec; e.tend_s = tend_s; e.tend_s_snwprd = snwprd; e.tend_s_snwevmlt = snwevmlt; e.tend_q = tend_q;
+    e.ntprprd = ntprprd; e.ntsnprd = ntsnprd; e.flxprec = io->flxprec; e.flxsnow = io->flxsnow; e.snow = io->snow;
+    if ((rc = colphys_zm_conv_evap_dev(ncol, pver, ztodt, &e, stream))) return rc;
+    if ((rc = update(t1, tend_s, q1, tend_q, nullptr, nullptr, nullptr, nullptr, 0))) return fail(rc, "physics_update launch failed");
+    if ((rc = geopotential())) return rc;
+
+    // ---- momtran on state1's winds (:814-836); u, v have not been touched yet, so state1 u, v = state u, v -------
+    HIPCHK(hipMemcpyAsync(winds, io->u, nM * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(winds + nM, io->v, nM * sizeof(double), hipMemcpyDeviceToDevice, st));
+    colphys_momtran_io m{};
+    m.winds = winds; m.mu = io->mu; m.md = io->md; m.du = io->du; m.eu = io->eu; m.ed = io->ed; m.dp = io->dp;
+    m.dsubcld = io->dsubcld; m.jt = io->jt; m.mx = io->maxg; m.ideep = io->ideep; m.lengath = io->lengath;
+    m.dqdt = wtend; m.pguall = pguall; m.pgdall = pgdall; m.icwu = icwu; m.icwd = icwd; m.seten = seten;
+    if ((rc = colphys_momtran_dev(ncol, pver, pcols, ztodt, &m, stream))) return rc;
+    // ptend_all%u, %v start here (nothing wrote them before); %s accumulates
+    if ((rc = update(t1, seten, nullptr, nullptr, io->u, wtend, io->v, wtend + nM, 4 | 8))) return fail(rc, "physics_update launch failed");
+    return geopotential();
 }
 
 int colphys_math_probe_dev(int kind, int64_t n, const double *x, double *y, void *stream)

@@ -163,6 +163,11 @@ int launch_modal_aero_lw(const AeroDev &A, int ncol, int pver, const colphys_mod
 int launch_physics_update(int ncol, int pver, double dt, double cpair, double qmin, const double *t_in,
                           const double *s_tend, double *t_out, const double *q_in, const double *q_tend, double *q_out,
                           const double *u_in, const double *u_tend, double *u_out, const double *v_in,
-                          const double *v_tend, double *v_out, hipStream_t st);
+                          const double *v_tend, double *v_out, hipStream_t st, double *sum_s = nullptr,
+                          double *sum_q = nullptr, double *sum_u = nullptr, double *sum_v = nullptr, int first = 0);
+int launch_zm_tend_diag(int ncol, int pver, int pcols, double gravit, const double *mcon, double *mconzm, const double *ps,
+                        const double *pmid, const double *mu, const double *md, const int32_t *jt, const int32_t *maxg,
+                        const int32_t *ideep, const int32_t *lengath, double *freqzm, double *pcont, double *pconb,
+                        double *mu_out, double *md_out, hipStream_t st);
 int launch_math_probe(int kind, int64_t n, const double *x, double *y, hipStream_t st);
 int launch_convtran(int ncol, int pver, int pcols, int ncnst, const colphys_convtran_io &io, hipStream_t st);

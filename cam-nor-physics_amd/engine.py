@@ -57,7 +57,8 @@ EXPORTED_SYMBOLS = [
     "colphys_zm_convr_dev", "colphys_zm_convr_chunks",
     "colphys_zm_conv_evap_dev", "colphys_zm_conv_evap_chunks",
     "colphys_momtran_dev", "colphys_momtran_chunks",
-    "colphys_convtran_dev", "colphys_convtran_chunks", "colphys_physics_update_dev", "colphys_aero_tables_set",
+    "colphys_convtran_dev", "colphys_convtran_chunks", "colphys_physics_update_dev", "colphys_zm_conv_tend_dev",
+    "colphys_aero_tables_set",
     "colphys_modal_aero_sw_dev", "colphys_modal_aero_lw_dev",
     "colphys_modal_aero_sw_chunks", "colphys_modal_aero_lw_chunks",
     "colphys_profile_enable", "colphys_profile_reset", "colphys_profile_get", "colphys_math_probe_dev",
@@ -188,6 +189,28 @@ class ColumnPhysics:
         self._check(self.lib.colphys_momtran_dev(C.c_int(n), C.c_int(pver), C.c_int(pcols), C.c_double(dt), C.byref(io),
                                                  self._stream()))
         return out
+
+    # ---- zm_conv_tend on resident data (zm_conv_intr.F90:441-905) -------------------------------------
+    def alloc_zm_conv_tend_out(self, n, pver, pcols):
+        t = self.torch
+        shape = {0: (n,), 1: (n, pver), 2: (n, pver + 1), 3: ((n + pcols - 1) // pcols,)}
+        o = {k: self.empty(*shape[lv]) for k, lv in {**abi.ZM_TEND_OUT, **abi.ZM_TEND_DIAG, **abi.ZM_TEND_STATE1}.items()}
+        o.update({k: self.empty(*shape[lv], dtype=t.int32) for k, lv in abi.ZM_TEND_OUT_I.items()})
+        o["status"] = self.empty(n, dtype=t.int32)
+        return o
+
+    def zm_conv_tend(self, state: dict, ztodt, pcols=16, dycore=abi.DYCORE_FV, qmin=1.0e-12, out=None):
+        """state: device tensors named as abi.ZM_TEND_IN; returns ptend_all, the pbuf fields, diagnostics and state1."""
+        n, pver = state["t"].shape
+        o = self.alloc_zm_conv_tend_out(n, pver, pcols) if out is None else out
+        io = abi.ZmConvTendIO()
+        for k in abi.ZM_TEND_IN:
+            setattr(io, k, _p(self._f64(state[k])))
+        for k, v in o.items():
+            setattr(io, k, _p(v, abi.PI) if v.dtype == self.torch.int32 else _p(v))
+        self._check(self.lib.colphys_zm_conv_tend_dev(C.c_int(n), C.c_int(pver), C.c_int(pcols), C.c_double(ztodt),
+                                                      C.c_int(dycore), C.c_double(qmin), C.byref(io), self._stream()))
+        return o
 
     # ---- convtran (zm_conv.F90:1976) ---------------------------------------------------------------
     def convtran(self, q, fracis, mu, md, du, eu, ed, dp, dpdry, jt, mx, ideep, lengath, doconvtran, isdry, dt, pcols=16,

@@ -272,6 +272,50 @@ int colphys_modal_aero_sw_chunks(int nchunks, int pcols, int pver, const int32_t
 int colphys_modal_aero_lw_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io);
 
 /* ---------------------------------------------------------------------------------------------------
+ * zm_conv_tend on resident data  (zm_conv_intr.F90:441-905, the part between the pbuf lookups and convtran1)
+ *
+ * The whole deep-convection tendency of a rank in ONE call, state1 never leaving the device:
+ *     zm_convr(state, delt = ztodt/2)                                            :662-675
+ *     mcon -> kg/m2/s, FREQZM, ZMMU/ZMMD scatter, PCONVT/PCONVB                  :685-731
+ *     ptend_all = ptend_loc; state1 = physics_update(state1, ptend_loc) + geopotential_t   :737-739
+ *     zm_conv_evap(state1, rprd, cld, ztodt; prec inout, snow)                   :764-771
+ *     evapcdp = dq/dt of evaporation; ptend_all += ptend_loc; physics_update + geopotential_t     :773, :802-806
+ *     momtran(winds = state1 u, v; ztodt)                                        :822-827
+ *     ptend_all += (wind tendencies, seten); physics_update + geopotential_t     :829-836
+ * All arrays are device pointers in the engine's layout ([ncol][pver], interfaces [ncol][pver+1], [ncol]); q is
+ * water vapour only.  Outputs under "diagnostics" and "state1" may be NULL.  Work arrays (ptend_loc, the kernels'
+ * diagnostic outputs that zm_conv_tend only hands to outfld) live in an internal grow-only device arena.
+ * The caller applies ptend_all to its own state afterwards, as tphysbc does (physpkg.F90:2838), and runs
+ * convtran on the gathered mass fluxes returned here (colphys_convtran_dev; zm_conv_intr.F90:875).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct colphys_zm_conv_tend_io {
+    /* physics_state */
+    const double *t, *q, *u, *v, *pmid, *pint, *pdel, *rpdel, *lnpint, *lnpmid, *zm, *zi;
+    const double *phis, *ps;                 /* [ncol] */
+    const double *rair, *zvir;               /* [ncol][pver], as geopotential_t takes them */
+    const double *pblh, *tpert, *landfrac;   /* [ncol] */
+    const double *cld;                       /* [ncol][pver], pbuf CLD at the old time level (:585) */
+    /* ptend_all */
+    double *ptend_s, *ptend_q, *ptend_u, *ptend_v;
+    /* surface / pbuf fields */
+    double *prec, *snow, *rliq, *rice, *jctop, *jcbot, *cape;      /* [ncol] */
+    double *ql, *rprd, *evapcdp, *dlf;                             /* ICWMRDP, RPRDDP, NEVAPR_DPCU, DLFZM */
+    double *mconzm, *flxprec, *flxsnow;                            /* [ncol][pver+1]: CMFMC_DP (kg/m2/s), DP_FLXPRC, DP_FLXSNW */
+    double *mu, *md, *du, *eu, *ed, *dp, *dsubcld;                 /* ZM_* gathered layout */
+    int32_t *jt, *maxg, *ideep, *lengath;
+    /* diagnostics (any may be NULL) */
+    double *freqzm, *pcont, *pconb;                                /* [ncol] */
+    double *mu_out, *md_out;                                       /* [ncol][pver], kg/m2/s */
+    /* state1 after the three updates (any may be NULL) */
+    double *t1, *q1, *u1, *v1, *zi1, *zm1;
+    int32_t *status;                                               /* [ncol] */
+} colphys_zm_conv_tend_io;
+
+/* qmin: lower bound physics_update's qneg3 applies to water vapour (constituents' qmin(1), 1e-12 in CAM) */
+int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dycore_kind, double qmin,
+                             const colphys_zm_conv_tend_io *io, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Measurement helper: average device time (ms) of each kernel family since the last reset, measured
  * with HIP events on the launch stream when profiling is switched on (bench.py's roofline leg).
  * ------------------------------------------------------------------------------------------------- */

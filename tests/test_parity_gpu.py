@@ -344,6 +344,69 @@ def test_ragged_column_counts_vs_c_oracle(ncol):
     assert_close("modal_aero_lw.tauxar", lw["tauxar"], lw_ref["tauxar"])
 
 
+@pytest.mark.parametrize("pver,ncol", [(32, 2000), (70, 300)])
+def test_zm_conv_tend_resident_matches_composed_calls(pver, ncol):
+    """colphys_zm_conv_tend_dev (zm_conv_intr.F90:441-905 on resident data) against the same sequence composed call by
+    call -- zm_convr, update, geopotential_t, zm_conv_evap, update, geopotential_t, momtran, update, geopotential_t --
+    and against numpy restatements of the host-side post-processing (:685-731) and of physics_ptend_sum."""
+    eng = engine(cases.default_params(pver))
+    st = synth.make_state(ncol, pver, 404)
+    c = synth.PHYSCONST
+    d = eng.dev
+    dt, pcols = synth.ZTODT, 16
+    S = {k: d(st[k]) for k in ("t", "q", "u", "v", "pmid", "pint", "pdel", "rpdel", "lnpint", "lnpmid", "zm", "zi", "phis",
+                               "rair", "zvir", "pblh", "tpert", "landfrac", "cld")}
+    S["ps"] = d(st["pint"][:, -1].copy())
+    o = to_np(eng.zm_conv_tend(S, dt, pcols=pcols))
+
+    z = to_np(eng.zm_convr(S["t"], S["q"], S["pblh"], S["zm"], S["phis"], S["zi"], S["pmid"], S["pint"], S["pdel"], 0.5 * dt,
+                           S["tpert"], S["landfrac"], pcols=pcols))
+    qmin = 1.0e-12
+    t1 = st["t"] + z["heat"] * dt / c["cpair"]
+    q1 = np.maximum(st["q"] + z["qtnd"] * dt, qmin)
+    prec = d(z["prec"].copy())
+    e = to_np(eng.zm_conv_evap(d(t1), S["pmid"], S["pdel"], d(q1), S["landfrac"], d(z["rprd"]), S["cld"], dt, prec))
+    t2 = t1 + e["tend_s"] * dt / c["cpair"]
+    q2 = np.maximum(q1 + e["tend_q"] * dt, qmin)
+    m = to_np(eng.momtran(d(np.stack([st["u"], st["v"]])), *[d(z[k]) for k in ("mu", "md", "du", "eu", "ed", "dp", "dsubcld")],
+                          *[d(z[k]) for k in ("jt", "maxg", "ideep", "lengath")], dt, pcols=pcols))
+    t3 = t2 + m["seten"] * dt / c["cpair"]
+    u3 = st["u"] + m["dqdt"][0] * dt
+    v3 = st["v"] + m["dqdt"][1] * dt
+    zi3, zm3 = eng.geopotential_t(S["lnpint"], S["lnpmid"], S["pint"], S["pmid"], S["pdel"], S["rpdel"], d(t3), d(q2), S["rair"],
+                                  c["gravit"], S["zvir"])
+
+    for k in ("ql", "rprd", "dlf", "mu", "md", "du", "eu", "ed", "dp", "dsubcld", "jt", "maxg", "ideep", "lengath", "cape",
+              "rliq", "rice", "jctop", "jcbot"):
+        assert np.array_equal(o[k], z[k]), k
+    assert np.array_equal(o["mconzm"], z["mcon"] * 100.0 / c["gravit"])
+    assert np.array_equal(o["prec"], e["prec"]) and np.array_equal(o["snow"], e["snow"])
+    assert np.array_equal(o["evapcdp"], e["tend_q"])
+    assert np.array_equal(o["flxprec"], e["flxprec"]) and np.array_equal(o["flxsnow"], e["flxsnow"])
+    assert np.array_equal(o["ptend_s"], (z["heat"] + e["tend_s"]) + m["seten"])
+    assert np.array_equal(o["ptend_q"], z["qtnd"] + e["tend_q"])
+    assert np.array_equal(o["ptend_u"], m["dqdt"][0]) and np.array_equal(o["ptend_v"], m["dqdt"][1])
+    assert np.array_equal(o["t1"], t3) and np.array_equal(o["q1"], q2)
+    assert np.array_equal(o["u1"], u3) and np.array_equal(o["v1"], v3)
+    assert np.array_equal(o["zi1"], zi3.cpu().numpy()) and np.array_equal(o["zm1"], zm3.cpu().numpy())
+    # host-side post-processing of zm_conv_tend, restated
+    freq = np.zeros(ncol); mu_out = np.zeros((ncol, pver)); md_out = np.zeros((ncol, pver))
+    pcont = st["pint"][:, -1].copy(); pconb = pcont.copy()
+    for ic, lg in enumerate(z["lengath"]):
+        for j in range(lg):
+            row = ic * pcols + j
+            ii = ic * pcols + z["ideep"][row] - 1
+            freq[ii] = 1.0
+            mu_out[ii] = z["mu"][row] * 100.0 / c["gravit"]
+            md_out[ii] = z["md"][row] * 100.0 / c["gravit"]
+            if z["maxg"][row] > z["jt"][row]:
+                pcont[ii] = st["pmid"][ii, z["jt"][row] - 1]
+                pconb[ii] = st["pmid"][ii, z["maxg"][row] - 1]
+    assert z["lengath"].sum() > 0
+    for k, r in (("freqzm", freq), ("mu_out", mu_out), ("md_out", md_out), ("pcont", pcont), ("pconb", pconb)):
+        assert np.array_equal(o[k], r), k
+
+
 # ---------------------------------------------------------------------------------------------------
 # (d) the device logarithms that stand where the reference calls its libm
 # ---------------------------------------------------------------------------------------------------
