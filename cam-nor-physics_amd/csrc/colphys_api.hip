@@ -585,6 +585,8 @@ int colphys_aero_tables_set(const colphys_aero_tables *tb)
         for (size_t i = 0; i < nm * ns; ++i) rd[i] = 1.0 / tb->specdens[i];
         bad |= up(rd.data(), 8 * nm * ns, (const void **)&A.rspecdens);
         A.rxrange = 1.0 / (tb->xrmax - tb->xrmin);
+        A.nspec_total = 0;
+        for (size_t m = 0; m < nm; ++m) A.nspec_total += tb->nspec[m];
     }
     if (bad) return fail(COLPHYS_ERR_HIP, "uploading packed aerosol table slices failed");
     g_aero_set = true;

@@ -52,6 +52,7 @@ struct AeroDev {
     const double *explnsigma;       // [nmodes] exp(2 ln(sigmag)^2), modal_aer_opt.F90:1553-1554
     const double *rspecdens;        // [nmodes][nspec_max] 1/specdens
     double rxrange;                 // 1/(xrmax - xrmin)
+    int nspec_total;                // sum of nspec over the modes (host mirror)
 };
 constexpr int AERO_NCP = 6;
 constexpr int AERO_TBLP = COLPHYS_PREFI * COLPHYS_PREFR * AERO_NCP;

@@ -4,29 +4,33 @@
 //   modal_aero_sw :485-1212, modal_aero_lw :1216-1469, modal_size_parameters :1538-1574.
 // (addfld/outfld history diagnostics stay on the host side; DESIGN.md "out of scope".)
 //
-// Every (column, level) cell is independent and modes only accumulate, so:
+// Every (column, level) cell is independent and modes only accumulate, so in both kernels here
 //   work item  = one cell; a block is 4 waves = 256 consecutive cells of the [ncol][pver] layout
 //                (coalesced reads of pdeldry / dgnumwet / qaerwat / specmmr);
-//   grid.y     = band group: the SW bands are split into groups so that the group's running sums
-//                tau, tau*w, tau*w*g, tau*w*g^2 for 256 cells fit in LDS next to the tables and three blocks
-//                share a CU (the per-(cell, mode) size/volume prologue is recomputed per group);
-//   LDS        = (a) the (mode, band) slice of the coefficient tables -- ext/abs/asm(5,7,10) + the two
-//                refractive-index grids -- because each cell gathers 4 corners x 5 coefficients x 3 tables
-//                per (mode, band) at data-dependent indices; coefficients padded 5 -> 6 so a corner is
-//                three 16-byte LDS reads.  The slices are packed ONCE on the host in exactly this image
-//                (colphys_aero_tables_set), so staging is a straight copy done by the LDS-DMA path
-//                (global_load_lds_dwordx4: no staging registers), DOUBLE-BUFFERED: the next slice is in
+//   LDS        = the (mode, band) slice of the coefficient tables -- ext/abs/asm(5,7,10) + the two
+//                refractive-index grids and their reciprocal interval widths -- because each cell gathers
+//                4 corners x 5 coefficients x 3 tables per (mode, band) at data-dependent indices; coefficients
+//                padded 5 -> 6 so a corner is three 16-byte LDS reads.  The slices are packed ONCE on the host in
+//                exactly this image (colphys_aero_tables_set), so staging is a straight copy done by the LDS-DMA
+//                path (global_load_lds_dwordx4: no staging registers), DOUBLE-BUFFERED: the next slice is in
 //                flight while the current one is used, one barrier per (mode, band);
-//                (b) the block's band accumulators [band][4][256 cells] (lane-contiguous, conflict-free);
 //   unit body  = one (mode, band) step is straight-line code: the grid search of table_interp is a
 //                branch-free scan against the grid held in SGPRs (scalar loads: the grid is wave-uniform);
-//                the first version's per-step LDS read + branch chain was the kernel's latency floor;
-//   order      = modes outer, bands inner: exactly the reference's accumulation order per output element.
+//                the first version's per-step LDS read + branch chain was the kernel's latency floor.
+// modal_aero_kernel<SW> (LW, and SW with more than four modes): modes outer, bands inner, the block's band
+//                accumulators [band][NOUT][256 cells] in LDS (lane-contiguous, conflict-free); grid.y = band group:
+//                the bands are split so that accumulators + slices fit AERO_LDS_CAP_KB and three blocks share a CU
+//                (the per-(cell, mode) size / volume prologue is recomputed per group).
+// modal_aero_sw_reg_kernel (SW): bands outer, modes inner, see there.
+// Both add a band's modes in the reference's order.
 // table_interp semantics: oracle/stubs/l0_arithmetic.F90 (parity-unpinned seam).
 #include "colphys_common.h"
 
 #ifndef AERO_MIN_WAVES
 #define AERO_MIN_WAVES 3                   // 3 waves / SIMD: the kernel needs ~136 VGPRs
+#endif
+#ifndef AERO_SW_WAVES
+#define AERO_SW_WAVES 3                    // bands-outer SW kernel: waves per SIMD the register budget is set for
 #endif
 #ifndef AERO_LDS_CAP_KB
 #define AERO_LDS_CAP_KB 53                 // three blocks per CU (A/B on MI355X: 53 KB x 3 beats 78 KB x 2)
@@ -295,20 +299,22 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
 
 // ------------------------------------------------------------------------------------------------------
 // SW, "bands outer, modes inner" (the default for up to 4 modes; -DAERO_SW_GROUPED selects the grouped kernel above): the
-// per-(cell, mode) state -- Chebyshev terms, species volumes, water / wet volume -- of ALL modes stays in registers, the
+// per-(cell, mode) state of ALL modes is computed once and kept -- Chebyshev terms, water / wet volume in registers, the
+// species volumes in a lane-private LDS array [species slot][cell] (packed through the modes: sum of nspec slots) -- the
 // four running sums of one band are four registers, and a band is written out as soon as its last mode has been added
 // (same order of additions per output element as the reference's modes-outer loop).  No LDS accumulators, no band
-// groups, no recomputed prologue: 16 % fewer VALU instructions than five band groups, at 247 VGPRs (two waves per
-// SIMD instead of three) and 20 KB of LDS per block; measured 1.40 -> 1.32 ms.
+// groups, no recomputed prologue: 16 % fewer VALU instructions than five band groups.  With the volumes in registers
+// the kernel needed 247 VGPRs (two waves per SIMD, 1.32 ms); with them in LDS it fits 168 (three waves, 1.24 ms).
 // ------------------------------------------------------------------------------------------------------
 constexpr int NMMAX = 4;
 
-__global__ __launch_bounds__(NT, 2) void modal_aero_sw_reg_kernel(AeroDev A, int ncol, int pver, colphys_modal_aero_io io)
+__global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(AeroDev A, int ncol, int pver, colphys_modal_aero_io io)
 {
     constexpr int NTAB = 3;
     constexpr int SLICE = aero_slice_doubles(NTAB);
     extern __shared__ double smem[];
     double *s_slice0 = smem;                           // two slices (double buffer)
+    double *s_vol = smem + 2 * SLICE + threadIdx.x;    // species volumes [slot][NT], slot = species counted through the modes
 
     const int nb = A.nswbands;
     const size_t L = (size_t)pver, F = (size_t)ncol * L, LP = L + 1;
@@ -326,30 +332,34 @@ __global__ __launch_bounds__(NT, 2) void modal_aero_sw_reg_kernel(AeroDev A, int
     const double mass = io.pdeldry[cc] * A.rga;        // :644
     int bad = 0;
 
-    double vol[NMMAX][NSMAX], cheb[NMMAX][NC], watervol[NMMAX], wetvol[NMMAX], wetinv[NMMAX], radsurf[NMMAX];
+    double cheb[NMMAX][NC], watervol[NMMAX], wetvol[NMMAX], wetinv[NMMAX], radsurf[NMMAX];
+    int voff[NMMAX + 1];
+    voff[0] = 0;
     bool small[NMMAX];
 #pragma unroll
     for (int m = 0; m < NMMAX; ++m) {
         watervol[m] = 0.0; wetvol[m] = 0.0; wetinv[m] = 0.0; radsurf[m] = 1.0; small[m] = true;
-#pragma unroll
-        for (int l = 0; l < NSMAX; ++l) vol[m][l] = 0.0;
+        voff[m + 1] = voff[m];
 #pragma unroll
         for (int nc = 0; nc < NC; ++nc) cheb[m][nc] = 0.0;
         if (m < A.nmodes) {
             const int nspec = A.nspec[m];
+            voff[m + 1] = voff[m] + nspec;
             const double dgn = io.dgnumwet[m * F + cc];
             const double qw = io.qaerwat[m * F + cc];
+            double v[NSMAX];
 #pragma unroll
             for (int l = 0; l < NSMAX; ++l)
-                if (l < nspec) vol[m][l] = io.specmmr[((size_t)m * A.nspec_max + l) * F + cc];
+                if (l < nspec) v[l] = io.specmmr[((size_t)m * A.nspec_max + l) * F + cc];
             double logradsurf;
             size_parameters(A, as_const(A.explnsigma)[m], dgn, radsurf[m], logradsurf, cheb[m]);
             double dryvol = 0.0;
 #pragma unroll
             for (int l = 0; l < NSMAX; ++l) {
                 if (l < nspec) {
-                    vol[m][l] = vol[m][l] * as_const(A.rspecdens)[m * A.nspec_max + l];
-                    dryvol = dryvol + vol[m][l];
+                    const double vl = v[l] * as_const(A.rspecdens)[m * A.nspec_max + l];
+                    s_vol[(voff[m] + l) * NT] = vl;             // own lane's column of the LDS array: no barrier needed
+                    dryvol = dryvol + vl;
                 }
             }
             watervol[m] = qw * rh2odens;
@@ -381,8 +391,9 @@ __global__ __launch_bounds__(NT, 2) void modal_aero_sw_reg_kernel(AeroDev A, int
 #pragma unroll
                 for (int l = 0; l < NSMAX; ++l) {
                     if (l < nspec) {
-                        cre = cre + vol[m][l] * ri[(size_t)l * nb * 2];
-                        cim = cim + vol[m][l] * ri[(size_t)l * nb * 2 + 1];
+                        const double vl = s_vol[(voff[m] + l) * NT];
+                        cre = cre + vl * ri[(size_t)l * nb * 2];
+                        cim = cim + vl * ri[(size_t)l * nb * 2 + 1];
                     }
                 }
                 cptr_t crefw = as_const(A.crefwsw + ib * 2);
@@ -449,7 +460,12 @@ static int launch_aero(bool sw, const AeroDev &A, int ncol, int pver, const colp
 #ifndef AERO_SW_GROUPED
     if (sw && A.nmodes <= NMMAX) {
         const dim3 g1((unsigned)((cells + NT - 1) / NT));
-        hipLaunchKernelGGL(modal_aero_sw_reg_kernel, g1, dim3(NT), 2 * slice * sizeof(double), st, A, ncol, pver, io);
+        // LDS: the slice double buffer + the species volumes of all modes, [sum of nspec][NT] (nspec lives on the device:
+        // size for the largest table the engine accepts would waste LDS, so the host mirror of nspec is used)
+        const size_t lds_reg = (2 * slice + (size_t)A.nspec_total * NT) * sizeof(double);
+        if (lds_reg > 64 * 1024)
+            hipFuncSetAttribute((const void *)modal_aero_sw_reg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+        hipLaunchKernelGGL(modal_aero_sw_reg_kernel, g1, dim3(NT), lds_reg, st, A, ncol, pver, io);
         return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
     }
 #endif
