@@ -51,15 +51,18 @@ def substep_bytes(L):
 
 PMC_KERNEL = {"geopotential_t": "geopotential_kernel", "zm_trigger": "zm_trigger_kernel", "zm_plume1": "zm_plume1_kernel",
               "zm_ascent2": "zm_ascent2_kernel", "zm_plume2": "zm_plume2_kernel",
-              "zm_conv_evap": "zm_conv_evap_kernel", "momtran": "momtran_wave_kernel", "modal_aero_sw": "modal_aero_kernel<true>",
+              "zm_conv_evap": "zm_conv_evap_kernel", "momtran": "momtran_wave_kernel", "modal_aero_sw": "modal_aero_sw_reg_kernel",
               "modal_aero_lw": "modal_aero_kernel<false>"}
 
 
-def pmc_traffic_gb(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command
-    (scripts/pmc_passes.sh -> profiles/*_pmc_summary.csv): (2*FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE reads
-    half the bytes of a coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM); calibrated here on
-    physics_update_kernel, whose byte count is known exactly.  None if no summary is committed."""
+def pmc_of(kernel):
+    """PMC-derived figures of `kernel` from the committed passes of this same command (scripts/pmc_passes.sh ->
+    profiles/*_pmc_summary.csv), or None:
+      traffic  HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE reads half the bytes of a coalesced
+               stream on gfx950 (MI355X_MICROARCH.md, HBM); calibrated here on physics_update_kernel, whose byte count
+               is known exactly (DESIGN.md 5);
+      valu     SIMD VALU utilisation = SQ_ACTIVE_INST_VALU * 4 cycles / (kernel cycles * 1 024 SIMDs): what bounds this
+               path (fp64 vector ALU), reported beside the HBM fraction the contract asks for."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")))
@@ -67,7 +70,11 @@ def pmc_traffic_gb(kernel):
         return None
     for r in csv.DictReader(open(files[-1])):
         if r["kernel"].startswith(PMC_KERNEL.get(kernel, "?")) and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
-            return round((2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024 / 1e9, 4), os.path.basename(files[-1])
+            out = {"traffic": round((2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024 / 1e9, 4),
+                   "source": os.path.basename(files[-1])}
+            if r.get("SQ_ACTIVE_INST_VALU") and r.get("GRBM_GUI_ACTIVE"):
+                out["valu"] = round(float(r["SQ_ACTIVE_INST_VALU"]) * 4.0 / (float(r["GRBM_GUI_ACTIVE"]) / 8.0 * 1024.0), 3)
+            return out
     return None
 
 
@@ -262,9 +269,11 @@ def main():
                     "substep_bytes_per_column": substep_bytes(pver),
                     "substep_hbm_frac": round(substep_bytes(pver) * value / world / 1e9 / HBM_PEAK_GBS, 6),
                     "note": "path is fp64-transcendental / latency bound, not HBM bound (SURVEY.md 0-4, 8d)"}
-        tr = pmc_traffic_gb(dom) if (args.ncol == 48602 and pver == 32) else None
-        if tr is not None:
-            roofline["traffic"], roofline["traffic_source"] = tr
+        pm = pmc_of(dom) if (args.ncol == 48602 and pver == 32) else None
+        if pm is not None:
+            roofline["traffic"], roofline["traffic_source"] = pm["traffic"], pm["source"]
+            if "valu" in pm:
+                roofline["valu_simd_util"] = pm["valu"]
         out = {
             "metric": baseline_metric(),
             "value": round(value, 1), "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
