@@ -647,6 +647,10 @@ __device__ void plume_load(const ZmDev &P, const ColIn &c, const PlumeLds &A, in
 }
 
 // cldprp :3024-4026 (non-microphysics path)
+// ENTRAINMENT_ONLY: the first call of the reference (:1032) is made for one thing, the entrainment profile eu that
+// sets the second ascent's rate (:1046-1078); everything cldprp computes after eu is final is overwritten by the second
+// call, so the first pass stops there.
+template <bool ENTRAINMENT_ONLY>
 __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, int jb, int lel, double landfrac, int lane,
                          PlumeIdx &o)
 {
@@ -859,6 +863,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
         }
     }
     SYNC();
+    if (ENTRAINMENT_ONLY) return;                                                            // eu is final (:3632-3646)
     PAR(k, msg + 2, pver) {                                                                  // :3649-3654
         A.tu[k] = (A.hu[k] - grav * A.zf[k] - (1.0 + dcol * tmelt) * rl * A.qu[k]) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * A.qu[k]));
     }
@@ -1099,7 +1104,7 @@ __global__ __launch_bounds__(WAVE) void zm_plume1_kernel(ZmDev P, int ncol, int 
     const ColIn c = make_colin(P, io, col, pver);
     plume_load(P, c, A, lane);
     PlumeIdx ix;
-    cldprp_w(P, pver, msg, A, ws.mx1[col], ws.lel1[col], c.landfrac, lane, ix);              // :1032
+    cldprp_w<true>(P, pver, msg, A, ws.mx1[col], ws.lel1[col], c.landfrac, lane, ix);        // :1032
     double dmpdz = -1.0;                                                                     // :1046-1078
     {
         double hk = 0.0, dmmx = 0.0, dmsm = 0.0;
@@ -1178,7 +1183,7 @@ __global__ __launch_bounds__(WAVE) void zm_plume2_kernel(ZmDev P, int ncol, int 
         if (k >= maxg) dsubcld = dsubcld + A.dp[k];
 
     PlumeIdx ix;
-    cldprp_w(P, pver, msg, A, maxg, lelg, c.landfrac, lane, ix);                             // :1216
+    cldprp_w<false>(P, pver, msg, A, maxg, lelg, c.landfrac, lane, ix);                      // :1216
     const int jt = ix.jt, mx = maxg;
 
     PAR(k, msg + 1, pver) {                                                                  // :1252-1262
