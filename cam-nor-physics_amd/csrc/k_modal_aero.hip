@@ -80,33 +80,30 @@ __device__ __forceinline__ Wght calcwghts(cptr_t g, const double *s_g, const dou
 
 // Bilinear table interpolation (table_interp) fused with the Chebyshev sum that consumes it:
 //     p = 0.5*c(1) + sum_{nc=2..5} cheb(nc)*c(nc)        (modal_aer_opt.F90:870-873, 882-887, 1390-1393)
-// with c(nc) the interpolated coefficient, evaluated in the reference's order.  tbl: LDS [NI][NR][NCP]; the
-// four corners are read as 16-byte pairs.
+// with c(nc) the bilinearly interpolated coefficient.  Both operations are linear, so the Chebyshev sum is taken at
+// each of the four corners first and the four sums are interpolated once (26 FMA-class instructions instead of 35;
+// a reassociation of the reference's order, covered by the optics' measured 3.5e-15 -- see the contraction note above).
+// tbl: LDS [NI][NR][NCP]; the four corners are read as 16-byte pairs.
 __device__ __forceinline__ double interp_cheb(const double *tbl, const Wght &wr, const Wght &wi, const double *cheb)
 {
     const double2 *p11 = reinterpret_cast<const double2 *>(tbl + (wi.ix1 * NR + wr.ix1) * NCP);
     const double2 *p21 = reinterpret_cast<const double2 *>(tbl + (wi.ix1 * NR + wr.ix2) * NCP);
     const double2 *p12 = reinterpret_cast<const double2 *>(tbl + (wi.ix2 * NR + wr.ix1) * NCP);
     const double2 *p22 = reinterpret_cast<const double2 *>(tbl + (wi.ix2 * NR + wr.ix2) * NCP);
-    double p = 0.0;
-#pragma unroll
-    for (int j = 0; j < NCP / 2; ++j) {
-        const double2 a = p11[j], b = p21[j], c = p12[j], d = p22[j];
-        {
-            const double fx1 = wr.wt1 * a.x + wr.wt2 * b.x;
-            const double fx2 = wr.wt1 * c.x + wr.wt2 * d.x;
-            const double r = wi.wt1 * fx1 + wi.wt2 * fx2;
-            if (j == 0) p = 0.5 * r;
-            else p = p + cheb[2 * j] * r;
-        }
-        if (2 * j + 1 < NC) {
-            const double fx1 = wr.wt1 * a.y + wr.wt2 * b.y;
-            const double fx2 = wr.wt1 * c.y + wr.wt2 * d.y;
-            const double r = wi.wt1 * fx1 + wi.wt2 * fx2;
-            p = p + cheb[2 * j + 1] * r;
-        }
-    }
-    return p;
+    auto corner = [&](const double2 *c) -> double {
+        const double2 a = c[0], b = c[1];
+        const double e = c[2].x;
+        double sum = 0.5 * a.x;
+        sum = sum + cheb[1] * a.y;
+        sum = sum + cheb[2] * b.x;
+        sum = sum + cheb[3] * b.y;
+        sum = sum + cheb[4] * e;
+        return sum;
+    };
+    const double s11 = corner(p11), s21 = corner(p21), s12 = corner(p12), s22 = corner(p22);
+    const double fx1 = wr.wt1 * s11 + wr.wt2 * s21;
+    const double fx2 = wr.wt1 * s12 + wr.wt2 * s22;
+    return wi.wt1 * fx1 + wi.wt2 * fx2;
 }
 
 __device__ __forceinline__ void size_parameters(const AeroDev &A, double explnsigma, double dgnumwet, double &radsurf,
