@@ -37,7 +37,7 @@
 #endif
 // Unlike the ZM kernels (Brent iterations with discrete stopping tests) the optics are straight polynomial /
 // bilinear arithmetic, so FMA contraction is allowed here: -8 % time; measured against the reference goldens the
-// worst relative error is 3.5e-15 with and 3.2e-15 without (scripts/parity_report.py).  -DAERO_NO_CONTRACT undoes it.
+// worst relative error is 4.9e-15 with (and with the corner-first interpolation below) and 3.2e-15 without (scripts/parity_report.py).  -DAERO_NO_CONTRACT undoes it.
 #ifndef AERO_NO_CONTRACT
 #pragma clang fp contract(fast)
 #endif
@@ -82,7 +82,7 @@ __device__ __forceinline__ Wght calcwghts(cptr_t g, const double *s_g, const dou
 //     p = 0.5*c(1) + sum_{nc=2..5} cheb(nc)*c(nc)        (modal_aer_opt.F90:870-873, 882-887, 1390-1393)
 // with c(nc) the bilinearly interpolated coefficient.  Both operations are linear, so the Chebyshev sum is taken at
 // each of the four corners first and the four sums are interpolated once (26 FMA-class instructions instead of 35;
-// a reassociation of the reference's order, covered by the optics' measured 3.5e-15 -- see the contraction note above).
+// a reassociation of the reference's order, covered by the optics' measured 4.9e-15 -- see the contraction note above).
 // tbl: LDS [NI][NR][NCP]; the four corners are read as 16-byte pairs.
 __device__ __forceinline__ double interp_cheb(const double *tbl, const Wght &wr, const Wght &wi, const double *cheb)
 {
