@@ -185,13 +185,16 @@ def test_evap_snow_paths_vs_reference_golden():
         assert_close("zm_conv_evap." + k, v, g["evap_" + k])
 
 
-def test_modal_aero_vs_c_oracle():
+@pytest.mark.parametrize("top_lev", [1, 4])
+def test_modal_aero_vs_c_oracle(top_lev):
+    """top_lev > 1 (clim_modal_aero_top_lev, modal_aer_opt.F90:731, 1345): levels above it keep the initial zeros"""
     from c_oracle import COracle
     pver, ncol = 32, 700
     params = cases.default_params(pver)
     eng = engine(params)
     co = COracle(params)
     props = synth.make_aero_props(5)
+    props["top_lev"] = top_lev
     st = synth.make_state(ncol, pver, 5)
     aer = synth.make_aero_state(ncol, pver, props, 5)
     eng.aero_tables_set(props, synth.PHYSCONST)
@@ -203,6 +206,9 @@ def test_modal_aero_vs_c_oracle():
     for k in ("tauxar", "wa", "ga", "fa"):
         assert_close("modal_aero_sw." + k, sw[k], sw_ref[k])
     assert_close("modal_aero_lw.tauxar", lw["tauxar"], lw_ref["tauxar"])
+    if top_lev > 1:
+        assert not sw["tauxar"][:, :, 1:top_lev].any() and not lw["tauxar"][:, :, :top_lev - 1].any()
+        assert sw["tauxar"][:, :, top_lev:].all()
 
 
 # ---------------------------------------------------------------------------------------------------
