@@ -587,6 +587,47 @@ __global__ __launch_bounds__(2 * TRIG_GROUPS_MAX * WAVE) void zm_trigger_kernel(
     }
 }
 
+// The same trigger with ONE wave per 64 columns doing both sweeps of a level back to back (buoyan_dilute_2w<.., PIPE =
+// false>): for column counts that fill the SIMDs on their own (ne120: 12 150 column groups) and for level counts
+// where the pipeline's barriers and its second copy of the launch-level search only cost (measured at ne120: 7.2 ms
+// fused, 9.2 ms paired).
+__global__ __launch_bounds__(WAVE) void zm_trigger_fused_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io,
+                                                               ZmWorkspace ws)
+{
+    CHAIN_PRIO();
+    extern __shared__ double smem[];            // [(pver+2)][WAVE] parcel virtual temperature / buoyancy
+    const int col0 = blockIdx.x * WAVE;
+    const int nb = min(WAVE, ncol - col0);
+    const int lane = threadIdx.x;
+    const int col = col0 + lane;
+    const size_t L = (size_t)pver, LP = (size_t)pver + 1;
+    {
+        double *mid[] = {io.qtnd, io.heat, io.cme, io.zdu, io.rprd, io.dlf, io.ql, io.dif, io.dnlf, io.dnif, io.eurt,
+                         io.mu, io.md, io.du, io.eu, io.ed, io.dp};
+        for (double *p : mid) block_fill(p + col0 * L, nb * L, 0.0);
+        block_fill(io.mcon + col0 * LP, nb * LP, 0.0);
+        block_fill(io.pflx + col0 * LP, nb * LP, 0.0);
+    }
+    if (lane >= nb) return;
+    io.prec[col] = 0.0; io.rliq[col] = 0.0; io.rice[col] = 0.0;
+    io.jctop[col] = pver; io.jcbot[col] = 1;
+    io.dsubcld[col] = 0.0; io.jt[col] = 0; io.maxg[col] = 0; io.ideep[col] = 0;
+    ws.deep[col] = 0;
+
+    const ColIn c = make_colin(P, io, col, pver);
+    const double pblt = pbl_top_index(c);
+    BuoyRes r;
+    buoyan_dilute_2w<false, false>(P, c, pblt, -P.tentrm, 0.0, 1, lane, smem + lane, nullptr, nullptr, nullptr, false, r);   // :544, 886
+
+    io.cape[col] = r.cape;
+    io.status[col] = r.status;
+    ws.cape1[col] = r.cape; ws.cin1[col] = r.cin; ws.lel1[col] = r.lel; ws.mx1[col] = r.mx;
+    if (r.cape > P.capelmt && r.cin < r.cape * P.cin_threshd) {     // :908-915
+        const int slot = atomicAdd(ws.count, 1);
+        ws.list[slot] = col;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Plume ensemble on ONE WAVE PER COLUMN (cldprp :3024-4026, closure :4028-4260, q1q2_pjr :4262-4421).
 //
@@ -1329,18 +1370,41 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     const int nchunks = (ncol + pcols - 1) / pcols;
     if (hipMemsetAsync(ws.count, 0, sizeof(int), st) != hipSuccess) return COLPHYS_ERR_HIP;
     if (ev) hipEventRecord(ev[0], st);
-    int groups = TRIG_GROUPS_MAX;                              // column groups (wave pairs) per trigger block
+    // trigger: wave pairs while the column groups alone leave SIMDs idle (four groups per block so that a pair shares a
+    // SIMD; fewer when the LDS profile is long, e.g. two at L70 -- still 9 % better in the overlapped substep there);
+    // one wave per group doing both sweeps once the groups fill the SIMDs on their own (measured with the optics
+    // running beside it: 48 602 columns 2.93 vs 3.01 ms, 97 202 columns 5.21 vs 5.26, 194 402 columns 10.24 vs 10.02,
+    // 777 602 columns 41.7 vs 39.0).  COLPHYS_TRIG_MODE = 1 / 2 forces paired / fused (experiments).
+    static int n_simd = 0;
+    if (!n_simd) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        n_simd = 4 * cus;
+    }
+    bool paired = nblk <= n_simd;
+    if (const char *e = getenv("COLPHYS_TRIG_MODE")) {
+        if (atoi(e) == 1) paired = true;
+        if (atoi(e) == 2) paired = false;
+    }
+    int groups = TRIG_GROUPS_MAX;
     while (groups > 1 && lds2 * groups > 150 * 1024) groups /= 2;
-    const int ntrig = (ncol + groups * WAVE - 1) / (groups * WAVE);
-    const size_t ldst = lds2 * groups;
-    if (ldst > 160 * 1024) return COLPHYS_ERR_UNSUPPORTED;
-    if (ldst > 64 * 1024) hipFuncSetAttribute((const void *)zm_trigger_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);
-    hipLaunchKernelGGL(zm_trigger_kernel, dim3(ntrig), dim3(2 * groups * WAVE), ldst, st, P, ncol, pver, groups, io, ws);
+    if (lds2 * groups > 160 * 1024) paired = false;
+    if (paired) {
+        const int ntrig = (ncol + groups * WAVE - 1) / (groups * WAVE);
+        const size_t ldst = lds2 * groups;
+        if (ldst > 64 * 1024) hipFuncSetAttribute((const void *)zm_trigger_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);
+        hipLaunchKernelGGL(zm_trigger_kernel, dim3(ntrig), dim3(2 * groups * WAVE), ldst, st, P, ncol, pver, groups, io, ws);
+    } else {
+        if (lds > 160 * 1024) return COLPHYS_ERR_UNSUPPORTED;
+        if (lds > 64 * 1024) hipFuncSetAttribute((const void *)zm_trigger_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(zm_trigger_fused_kernel, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, io, ws);
+    }
     if (ev) { hipEventRecord(ev[1], st); hipEventRecord(ev[2], st); }
     const size_t lds_w = (size_t)(PLUME_NARR + 2) * (pver + 2) * sizeof(double);
     const int nper = ncol < 256 * 12 ? ncol : 256 * 12;       // persistent: ~12 waves per CU fit in LDS at L32
     hipLaunchKernelGGL(zm_plume1_kernel, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, io, ws);
     if (ev) { hipEventRecord(ev[3], st); hipEventRecord(ev[4], st); }
+    if (lds2 > 64 * 1024) hipFuncSetAttribute((const void *)zm_ascent2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(zm_ascent2_kernel, dim3(nblk), dim3(2 * WAVE), lds2, st, P, ncol, pver, io, ws);
     if (ev) { hipEventRecord(ev[5], st); hipEventRecord(ev[6], st); }
     hipLaunchKernelGGL(zm_plume2_kernel, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, delt, io, ws);
