@@ -59,8 +59,13 @@ def check_zm(o, ref, ncol, pcols=cases.PCOLS):
 # ---------------------------------------------------------------------------------------------------
 # (a) golden fixtures = outputs of the reference Fortran
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("trig_mode", ["auto", "fused"])
 @pytest.mark.parametrize("name", cases.ZM_GOLDEN)
-def test_zm_convr_vs_reference_golden(name):
+def test_zm_convr_vs_reference_golden(name, trig_mode, monkeypatch):
+    """both mappings of the first ascent: wave pairs (what these column counts select) and the single-wave kernel
+    that takes over when the column groups fill the SIMDs (forced here through COLPHYS_TRIG_MODE)"""
+    if trig_mode == "fused":
+        monkeypatch.setenv("COLPHYS_TRIG_MODE", "2")
     g = cases.load_golden(name)
     eng = engine(cases.golden_params(g))
     o = run_zm(eng, cases.zm_args_from_golden(g))
