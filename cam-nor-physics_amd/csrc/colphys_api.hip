@@ -427,7 +427,7 @@ int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dy
            *mcon = w.take<double>(nI), *pflx = w.take<double>(nI);
     double *tend_s = w.take<double>(nM), *snwprd = w.take<double>(nM), *snwevmlt = w.take<double>(nM), *tend_q = io->evapcdp,
            *ntprprd = w.take<double>(nM), *ntsnprd = w.take<double>(nM);
-    double *winds = w.take<double>(2 * nM), *wtend = w.take<double>(2 * nM), *pguall = w.take<double>(2 * nM),
+    double *wtend = w.take<double>(2 * nM), *pguall = w.take<double>(2 * nM),
            *pgdall = w.take<double>(2 * nM), *icwu = w.take<double>(2 * nM), *icwd = w.take<double>(2 * nM),
            *seten = w.take<double>(nM);
     double *t1 = io->t1 ? io->t1 : w.take<double>(nM), *q1 = io->q1 ? io->q1 : w.take<double>(nM);
@@ -478,13 +478,14 @@ int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dy
     if ((rc = geopotential())) return rc;
 
     // ---- momtran on state1's winds (:814-836); u, v have not been touched yet, so state1 u, v = state u, v -------
-    HIPCHK(hipMemcpyAsync(winds, io->u, nM * sizeof(double), hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(winds + nM, io->v, nM * sizeof(double), hipMemcpyDeviceToDevice, st));
     colphys_momtran_io m{};
-    m.winds = winds; m.mu = io->mu; m.md = io->md; m.du = io->du; m.eu = io->eu; m.ed = io->ed; m.dp = io->dp;
+    m.winds = io->u; m.mu = io->mu; m.md = io->md; m.du = io->du; m.eu = io->eu; m.ed = io->ed; m.dp = io->dp;
     m.dsubcld = io->dsubcld; m.jt = io->jt; m.mx = io->maxg; m.ideep = io->ideep; m.lengath = io->lengath;
     m.dqdt = wtend; m.pguall = pguall; m.pgdall = pgdall; m.icwu = icwu; m.icwd = icwd; m.seten = seten;
-    if ((rc = colphys_momtran_dev(ncol, pver, pcols, ztodt, &m, stream))) return rc;
+    {
+        ProfScope ps(COLPHYS_K_MOMTRAN, st);
+        if ((rc = launch_momtran(g_P, ncol, pver, pcols, ztodt, m, st, io->v))) return fail(rc, "momtran launch failed");
+    }
     // ptend_all%u, %v start here (nothing wrote them before); %s accumulates
     if ((rc = update(t1, seten, nullptr, nullptr, io->u, wtend, io->v, wtend + nM, 4 | 8))) return fail(rc, "physics_update launch failed");
     return geopotential();

@@ -158,7 +158,9 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
 
 int launch_zm_conv_evap(const ZmDev &P, const double *estbl_dev, int ncol, int pver, double deltat,
                         const colphys_zm_conv_evap_io &io, hipStream_t st);
-int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, const colphys_momtran_io &io, hipStream_t st);
+// winds_v: v in its own [ncol][pver] array (then io.winds holds u only), or null for the stacked [2][ncol][pver] layout
+int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, const colphys_momtran_io &io, hipStream_t st,
+                   const double *winds_v = nullptr);
 int launch_modal_aero_sw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);
 int launch_modal_aero_lw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);
 int launch_physics_update(int ncol, int pver, double dt, double cpair, double qmin, const double *t_in,

@@ -8,8 +8,9 @@
 //   - the two genuine recurrences (in-cloud updraft wind, bottom-up :2563-2575; downdraft wind, top-down
 //     :2579-2589) are walked serially by lane 0 in the reference's order, in LDS;
 //   - results leave as contiguous rows.
+// The chunk's block first writes the initial values of the chunk's full-layout outputs (:2429-2443).
 // A thread-per-column mapping of the same work (round-1 first version) kept 13 private profiles in scratch and
-// ran 80 waves for 0.33 ms; this one runs ~5 000 short waves.
+// ran 80 waves for 0.33 ms.
 #include "colphys_common.h"
 
 namespace {
@@ -17,16 +18,30 @@ namespace {
 constexpr int NT = WAVE;
 
 __global__ __launch_bounds__(NT) void momtran_wave_kernel(ZmDev P, int ncol, int pver, int pcols, double dt,
-                                                         colphys_momtran_io io)
+                                                         colphys_momtran_io io, const double *winds_v)
 {
     CHAIN_PRIO();
     extern __shared__ double smem[];
     const int ic = blockIdx.x, c0 = ic * pcols;               // one block per host chunk, looping over its gathered rows
     const int il2g = io.lengath[ic];
+    const size_t L = (size_t)pver, F = (size_t)ncol * L;
+    const double *wind[2] = {io.winds, winds_v ? winds_v : io.winds + F};   // u, v (v may live in its own array)
+    {   // initialisation of the chunk's full-layout outputs (:2429-2443): contiguous [nc][pver] runs, coalesced
+        const int nc = min(pcols, ncol - c0);
+        const size_t base = (size_t)c0 * L, n = (size_t)nc * L;
+        for (size_t i = threadIdx.x; i < n; i += NT) {
+            for (int m = 0; m < 2; ++m) {
+                const size_t o = m * F + base + i;
+                const double w = wind[m][base + i];
+                io.pguall[o] = 0.0; io.pgdall[o] = 0.0; io.dqdt[o] = 0.0; io.icwu[o] = w; io.icwd[o] = w;
+            }
+            io.seten[base + i] = 0.0;
+        }
+    }
     if (il2g <= 0) return;                                    // block-uniform
+    __syncthreads();                                          // the rows below overwrite parts of what was just initialised
     const int lane = threadIdx.x;
     const int LD = pver + 2;                                  // 1-based profiles, [0] and [pver+1] as guards
-    const size_t L = (size_t)pver, F = (size_t)ncol * L;
     const double mbsth = 1.e-15;
 
     double *s_mu = smem, *s_md = s_mu + LD, *s_du = s_md + LD, *s_eu = s_du + LD, *s_ed = s_eu + LD, *s_dp = s_ed + LD;
@@ -53,7 +68,7 @@ __global__ __launch_bounds__(NT) void momtran_wave_kernel(ZmDev P, int ncol, int
         const size_t g = (size_t)row * L + (k - 1);
         s_mu[k] = io.mu[g]; s_md[k] = io.md[g]; s_du[k] = io.du[g]; s_eu[k] = io.eu[g]; s_ed[k] = io.ed[g]; s_dp[k] = io.dp[g];
         for (int m = 0; m < 2; ++m) {
-            s_c[m * LD + k] = io.winds[m * F + ii * L + (k - 1)];                // :2461-2466
+            s_c[m * LD + k] = wind[m][ii * L + (k - 1)];                         // :2461-2466
             s_mf[m * LD + k] = 0.0; s_wf[m * LD + k] = 0.0;                      // :2436-2438
         }
     }
@@ -157,27 +172,13 @@ __global__ __launch_bounds__(NT) void momtran_wave_kernel(ZmDev P, int ncol, int
     }
 }
 
-// initialisation of the full-layout outputs (:2429-2443), element-wise
-__global__ void momtran_init_kernel(size_t n2, size_t n1, colphys_momtran_io io)
-{
-    CHAIN_PRIO();
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-        const double w = io.winds[i];
-        io.pguall[i] = 0.0; io.pgdall[i] = 0.0; io.dqdt[i] = 0.0; io.icwu[i] = w; io.icwd[i] = w;
-        if (i < n1) io.seten[i] = 0.0;
-    }
-}
-
 }  // namespace
 
-int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, const colphys_momtran_io &io, hipStream_t st)
+int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, const colphys_momtran_io &io, hipStream_t st,
+                   const double *winds_v)
 {
-    const size_t n1 = (size_t)ncol * pver, n2 = 2 * n1;
-    const int iblk = (int)((n2 + 255) / 256 < 2048 ? (n2 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(momtran_init_kernel, dim3(iblk), dim3(256), 0, st, n2, n1, io);
     const size_t lds = (size_t)(6 + 2 * 8) * (pver + 2) * sizeof(double);
     const int nchunks = (ncol + pcols - 1) / pcols;
-    hipLaunchKernelGGL(momtran_wave_kernel, dim3(nchunks), dim3(NT), lds, st, P, ncol, pver, pcols, dt, io);
+    hipLaunchKernelGGL(momtran_wave_kernel, dim3(nchunks), dim3(NT), lds, st, P, ncol, pver, pcols, dt, io, winds_v);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
