@@ -298,7 +298,8 @@ int colphys_geopotential_t_dev(int ncol, int pver, int dycore_kind, int nq, int 
     return rc ? fail(rc, "geopotential_t launch failed") : COLPHYS_OK;
 }
 
-int colphys_zm_convr_dev(int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io *io, void *stream)
+static int zm_convr_impl(int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io *io, void *stream,
+                         const ZmTendDiag *diag)
 {
     int rc;
     if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
@@ -321,7 +322,7 @@ int colphys_zm_convr_dev(int ncol, int pver, int pcols, double delt, const colph
     }
     hipEvent_t ev[8];
     if (g_prof) for (auto &e : ev) e = ev_get();
-    rc = launch_zm_convr(g_P, ncol, pver, pcols, delt, *io, ws, st, g_prof ? ev : nullptr);
+    rc = launch_zm_convr(g_P, ncol, pver, pcols, delt, *io, ws, st, g_prof ? ev : nullptr, diag);
     if (g_prof) {
         g_pending.push_back({COLPHYS_K_ZM_TRIGGER, ev[0], ev[1]});
         g_pending.push_back({COLPHYS_K_ZM_PLUME1, ev[2], ev[3]});
@@ -329,6 +330,11 @@ int colphys_zm_convr_dev(int ncol, int pver, int pcols, double delt, const colph
         g_pending.push_back({COLPHYS_K_ZM_PLUME2, ev[6], ev[7]});
     }
     return rc ? fail(rc, "zm_convr launch failed") : COLPHYS_OK;
+}
+
+int colphys_zm_convr_dev(int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io *io, void *stream)
+{
+    return zm_convr_impl(ncol, pver, pcols, delt, io, stream, nullptr);
 }
 
 int colphys_zm_conv_evap_dev(int ncol, int pver, double deltat, const colphys_zm_conv_evap_io *io, void *stream)
@@ -443,12 +449,11 @@ int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dy
     c.prec = io->prec; c.jctop = io->jctop; c.jcbot = io->jcbot; c.cape = io->cape; c.rliq = io->rliq; c.rice = io->rice;
     c.mu = io->mu; c.md = io->md; c.du = io->du; c.eu = io->eu; c.ed = io->ed; c.dp = io->dp; c.dsubcld = io->dsubcld;
     c.jt = io->jt; c.maxg = io->maxg; c.ideep = io->ideep; c.lengath = io->lengath; c.status = io->status;
-    if ((rc = colphys_zm_convr_dev(ncol, pver, pcols, 0.5 * ztodt, &c, stream))) return rc;
-
-    // ---- mass flux units and the gathered diagnostics (:685-731) --------------------------------------------
-    if ((rc = launch_zm_tend_diag(ncol, pver, pcols, g_P.gravit, mcon, io->mconzm, io->ps, io->pmid, io->mu, io->md, io->jt,
-                                  io->maxg, io->ideep, io->lengath, io->freqzm, io->pcont, io->pconb, io->mu_out, io->md_out, st)))
-        return fail(rc, "zm_conv_tend diagnostics launch failed");
+    // ... with the mass-flux units and the gathered diagnostics (:685-731) done by its gather kernel
+    ZmTendDiag dg{};
+    dg.enabled = 1; dg.gravit = g_P.gravit; dg.mconzm = io->mconzm; dg.ps = io->ps; dg.pmid = io->pmid;
+    dg.freqzm = io->freqzm; dg.pcont = io->pcont; dg.pconb = io->pconb; dg.mu_out = io->mu_out; dg.md_out = io->md_out;
+    if ((rc = zm_convr_impl(ncol, pver, pcols, 0.5 * ztodt, &c, stream, &dg))) return rc;
 
     auto update = [&](const double *ti, const double *s, const double *qi, const double *qt, const double *ui, const double *ut,
                       const double *vi, const double *vt, int first) -> int {

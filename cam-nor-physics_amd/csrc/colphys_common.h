@@ -153,8 +153,18 @@ struct ZmWorkspace {            // device scratch owned by the API layer (grow-o
     int *lcl2, *lel2, *mx2, *retrig; // [ncol]
     double *tp2, *qstp2;            // [ncol][pver]
 };
+// zm_conv_tend's host-side post-processing of zm_convr (zm_conv_intr.F90:685-731), done by the gather kernel when asked:
+// mass flux to kg/m2/s, FREQZM, ZMMU/ZMMD, PCONVT/PCONVB (diagnostic pointers may be null)
+struct ZmTendDiag {
+    int enabled;
+    double gravit;
+    double *mconzm;
+    const double *ps, *pmid;
+    double *freqzm, *pcont, *pconb, *mu_out, *md_out;
+};
 int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io &io,
-                    const ZmWorkspace &ws, hipStream_t st, hipEvent_t *ev /* 8 events or null */);
+                    const ZmWorkspace &ws, hipStream_t st, hipEvent_t *ev /* 8 events or null */,
+                    const ZmTendDiag *diag = nullptr);
 
 int launch_zm_conv_evap(const ZmDev &P, const double *estbl_dev, int ncol, int pver, double deltat,
                         const colphys_zm_conv_evap_io &io, hipStream_t st);
@@ -168,9 +178,5 @@ int launch_physics_update(int ncol, int pver, double dt, double cpair, double qm
                           const double *u_in, const double *u_tend, double *u_out, const double *v_in,
                           const double *v_tend, double *v_out, hipStream_t st, double *sum_s = nullptr,
                           double *sum_q = nullptr, double *sum_u = nullptr, double *sum_v = nullptr, int first = 0);
-int launch_zm_tend_diag(int ncol, int pver, int pcols, double gravit, const double *mcon, double *mconzm, const double *ps,
-                        const double *pmid, const double *mu, const double *md, const int32_t *jt, const int32_t *maxg,
-                        const int32_t *ideep, const int32_t *lengath, double *freqzm, double *pcont, double *pconb,
-                        double *mu_out, double *md_out, hipStream_t st);
 int launch_math_probe(int kind, int64_t n, const double *x, double *y, hipStream_t st);
 int launch_convtran(int ncol, int pver, int pcols, int ncnst, const colphys_convtran_io &io, hipStream_t st);

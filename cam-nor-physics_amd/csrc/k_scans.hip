@@ -373,57 +373,6 @@ __global__ void physics_update_kernel(size_t n, double dt, double cpair, double 
     }
 }
 
-// zm_conv_tend's host-side post-processing of zm_convr (zm_conv_intr.F90:685-731), part 1, element-wise:
-// mass flux to kg/m2/s, initial values of the scattered diagnostics
-__global__ void zm_tend_diag_init_kernel(int ncol, int pver, double gravit, const double *__restrict__ mcon,
-                                         double *__restrict__ mconzm, const double *__restrict__ ps, double *freqzm,
-                                         double *pcont, double *pconb, double *mu_out, double *md_out)
-{
-    CHAIN_PRIO();
-    const size_t nI = (size_t)ncol * (pver + 1), nM = (size_t)ncol * pver;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nI; i += stride) {
-        mconzm[i] = mcon[i] * 100.0 / gravit;                               // :691-692
-        if (i < nM) {
-            if (mu_out) mu_out[i] = 0.0;                                    // :575-576
-            if (md_out) md_out[i] = 0.0;
-        }
-        if (i < (size_t)ncol) {
-            if (freqzm) freqzm[i] = 0.0;                                    // :685
-            if (pcont) pcont[i] = ps[i];                                    // :722-723
-            if (pconb) pconb[i] = ps[i];
-        }
-    }
-}
-// part 2, one wave per host chunk over its gathered columns: the scatters through ideep
-__global__ __launch_bounds__(WAVE) void zm_tend_diag_scatter_kernel(int ncol, int pver, int pcols, double gravit,
-                                                                   const double *__restrict__ pmid, const double *__restrict__ mu,
-                                                                   const double *__restrict__ md, const int32_t *__restrict__ jt,
-                                                                   const int32_t *__restrict__ maxg, const int32_t *__restrict__ ideep,
-                                                                   const int32_t *__restrict__ lengath, double *freqzm, double *pcont,
-                                                                   double *pconb, double *mu_out, double *md_out)
-{
-    CHAIN_PRIO();
-    const int ic = blockIdx.x, c0 = ic * pcols;
-    const int n = lengath[ic];
-    const size_t L = (size_t)pver;
-    for (int slot = 0; slot < n; ++slot) {
-        const int row = c0 + slot;
-        const size_t ii = (size_t)(c0 + ideep[row] - 1);
-        for (int k = threadIdx.x; k < pver; k += WAVE) {
-            if (mu_out) mu_out[ii * L + k] = mu[(size_t)row * L + k] * 100.0 / gravit;     // :700-706
-            if (md_out) md_out[ii * L + k] = md[(size_t)row * L + k] * 100.0 / gravit;
-        }
-        if (threadIdx.x == 0) {
-            if (freqzm) freqzm[ii] = 1.0;                                   // :686-688
-            if (maxg[row] > jt[row]) {                                      // :724-729
-                if (pcont) pcont[ii] = pmid[ii * L + (jt[row] - 1)];
-                if (pconb) pconb[ii] = pmid[ii * L + (maxg[row] - 1)];
-            }
-        }
-    }
-}
-
 inline int set_lds(const void *fn, size_t bytes)
 {
     if (bytes > 64 * 1024)
@@ -470,23 +419,6 @@ int launch_physics_update(int ncol, int pver, double dt, double cpair, double qm
     const int nblk = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(physics_update_kernel, dim3(nblk), dim3(256), 0, st, n, dt, cpair, qmin, t_in, s_tend, t_out, q_in,
                        q_tend, q_out, u_in, u_tend, u_out, v_in, v_tend, v_out, sum_s, sum_q, sum_u, sum_v, first);
-    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
-}
-
-int launch_zm_tend_diag(int ncol, int pver, int pcols, double gravit, const double *mcon, double *mconzm, const double *ps,
-                        const double *pmid, const double *mu, const double *md, const int32_t *jt, const int32_t *maxg,
-                        const int32_t *ideep, const int32_t *lengath, double *freqzm, double *pcont, double *pconb,
-                        double *mu_out, double *md_out, hipStream_t st)
-{
-    const size_t n = (size_t)ncol * (pver + 1);
-    const int nblk = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(zm_tend_diag_init_kernel, dim3(nblk), dim3(256), 0, st, ncol, pver, gravit, mcon, mconzm, ps, freqzm,
-                       pcont, pconb, mu_out, md_out);
-    if (freqzm || pcont || pconb || mu_out || md_out) {
-        const int nchunks = (ncol + pcols - 1) / pcols;
-        hipLaunchKernelGGL(zm_tend_diag_scatter_kernel, dim3(nchunks), dim3(WAVE), 0, st, ncol, pver, pcols, gravit, pmid, mu,
-                           md, jt, maxg, ideep, lengath, freqzm, pcont, pconb, mu_out, md_out);
-    }
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
 

@@ -1325,7 +1325,8 @@ __global__ __launch_bounds__(WAVE) void zm_plume2_kernel(ZmDev P, int ncol, int 
 // ------------------------------------------------------------------------------------------------------
 // Kernel 3: per-chunk ascending compaction into the reference's gathered layout
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void zm_gather_kernel(int ncol, int pver, int pcols, colphys_zm_convr_io io, ZmWorkspace ws)
+__global__ __launch_bounds__(WAVE) void zm_gather_kernel(int ncol, int pver, int pcols, colphys_zm_convr_io io, ZmWorkspace ws,
+                                                        ZmTendDiag dg)
 {
     CHAIN_PRIO();
     __shared__ int s_src[1024];
@@ -1356,12 +1357,38 @@ __global__ __launch_bounds__(WAVE) void zm_gather_kernel(int ncol, int pver, int
         io.maxg[c0 + j] = ws.maxg_f[src];
         io.ideep[c0 + j] = s_src[j] + 1;
     }
+    if (!dg.enabled) return;
+    // zm_conv_tend's post-processing (zm_conv_intr.F90:685-731) for the chunk's columns.  The scatters through ideep are
+    // reads of the full-layout copies here: a deep column's own mu / md / jt / maxg.
+    const size_t LP = L + 1;
+    for (size_t i = threadIdx.x; i < (size_t)nc * LP; i += blockDim.x)
+        dg.mconzm[(size_t)c0 * LP + i] = io.mcon[(size_t)c0 * LP + i] * 100.0 / dg.gravit;          // :691-692
+    if (dg.mu_out || dg.md_out) {
+        for (size_t i = threadIdx.x; i < (size_t)nc * L; i += blockDim.x) {                          // :575-576, 700-706
+            const size_t g = (size_t)c0 * L + i;
+            const bool deep = ws.deep[c0 + (int)(i / L)] != 0;
+            if (dg.mu_out) dg.mu_out[g] = deep ? ws.mu_f[g] * 100.0 / dg.gravit : 0.0;
+            if (dg.md_out) dg.md_out[g] = deep ? ws.md_f[g] * 100.0 / dg.gravit : 0.0;
+        }
+    }
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+        const int col = c0 + i;
+        const bool deep = ws.deep[col] != 0;
+        if (dg.freqzm) dg.freqzm[col] = deep ? 1.0 : 0.0;                                            // :685-688
+        double pt = dg.ps[col], pb = dg.ps[col];                                                     // :722-729
+        if (deep && ws.maxg_f[col] > ws.jt_f[col]) {
+            pt = dg.pmid[(size_t)col * L + (ws.jt_f[col] - 1)];
+            pb = dg.pmid[(size_t)col * L + (ws.maxg_f[col] - 1)];
+        }
+        if (dg.pcont) dg.pcont[col] = pt;
+        if (dg.pconb) dg.pconb[col] = pb;
+    }
 }
 
 }  // namespace
 
 int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io &io,
-                    const ZmWorkspace &ws, hipStream_t st, hipEvent_t *ev)
+                    const ZmWorkspace &ws, hipStream_t st, hipEvent_t *ev, const ZmTendDiag *diag)
 {
     if (pcols > 1024) return COLPHYS_ERR_ARG;
     const int nblk = (ncol + WAVE - 1) / WAVE;
@@ -1408,7 +1435,9 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     hipLaunchKernelGGL(zm_ascent2_kernel, dim3(nblk), dim3(2 * WAVE), lds2, st, P, ncol, pver, io, ws);
     if (ev) { hipEventRecord(ev[5], st); hipEventRecord(ev[6], st); }
     hipLaunchKernelGGL(zm_plume2_kernel, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, delt, io, ws);
-    hipLaunchKernelGGL(zm_gather_kernel, dim3(nchunks), dim3(WAVE), 0, st, ncol, pver, pcols, io, ws);
+    ZmTendDiag dg{};
+    if (diag) dg = *diag;
+    hipLaunchKernelGGL(zm_gather_kernel, dim3(nchunks), dim3(WAVE), 0, st, ncol, pver, pcols, io, ws, dg);
     if (ev) hipEventRecord(ev[7], st);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
