@@ -20,6 +20,10 @@
 namespace {
 
 constexpr int TILE = 32;      // columns per block
+#ifndef EVAP_TILE
+#define EVAP_TILE 16     // 34 KB of LDS per block at L32: fits the room ONE retiring optics block leaves (A/B: 32 -> 16 columns, substep 2.66 -> 2.58 ms)
+#endif
+constexpr int ETILE = EVAP_TILE;   // zm_conv_evap: columns per block (8 LDS tiles of [ETILE][pver])
 constexpr int NT = 64;        // threads per block (one wave): all lanes move data, lanes < TILE scan
 
 __device__ __forceinline__ int ldk_of(int nlev) { return (nlev & 1) ? nlev : nlev + 1; }
@@ -52,7 +56,10 @@ __device__ __forceinline__ void tile_out(double *g, const double *s, int nc, int
 //   Phase 3: coalesced store of the two tiles.
 //   LDS = 2 tiles: 34 KB for 64 columns x L32 => 4 blocks per CU; all 64 lanes scan.
 // ------------------------------------------------------------------------------------------------------
-constexpr int GT = 64;        // columns per block
+#ifndef GEO_TILE
+#define GEO_TILE 32      // 17 KB of LDS per block at L32 (A/B 64 -> 32 columns: 0.031 -> 0.028 ms alone, substep -0.5 %)
+#endif
+constexpr int GT = GEO_TILE;  // columns per block
 constexpr int GNT = 256;      // threads per block: four waves move data (8 flat-index steps at L32), one wave scans
 
 __global__ __launch_bounds__(GNT) void geopotential_kernel(int ncol, int pver, int dycore_kind, int nspecies,
@@ -135,20 +142,20 @@ __global__ __launch_bounds__(ENT) void zm_conv_evap_kernel(ZmDev P, const double
     CHAIN_PRIO();
     extern __shared__ double smem[];
     __shared__ double s_estbl[COLPHYS_PLENEST + 1];
-    const int col0 = blockIdx.x * TILE;
-    const int nc = min(TILE, ncol - col0);
+    const int col0 = blockIdx.x * ETILE;
+    const int nc = min(ETILE, ncol - col0);
     const int pverp = pver + 1;
     const int ld = ldk_of(pver), ldp = ldk_of(pverp);
     const size_t L = (size_t)pver, LP = (size_t)pverp;
 
     double *sT = smem;                 // t        -> tend_s
-    double *sPM = sT + TILE * ld;      // pmid     -> tend_s_snwprd
-    double *sPD = sPM + TILE * ld;     // pdel     -> tend_s_snwevmlt
-    double *sQ = sPD + TILE * ld;      // q        -> tend_q
-    double *sPR = sQ + TILE * ld;      // prdprec  -> ntprprd
-    double *sCL = sPR + TILE * ld;     // cldfrc   -> ntsnprd
-    double *sFP = sCL + TILE * ld;     // flxprec [ldp]
-    double *sFS = sFP + TILE * ldp;    // flxsnow [ldp]
+    double *sPM = sT + ETILE * ld;      // pmid     -> tend_s_snwprd
+    double *sPD = sPM + ETILE * ld;     // pdel     -> tend_s_snwevmlt
+    double *sQ = sPD + ETILE * ld;      // q        -> tend_q
+    double *sPR = sQ + ETILE * ld;      // prdprec  -> ntprprd
+    double *sCL = sPR + ETILE * ld;     // cldfrc   -> ntsnprd
+    double *sFP = sCL + ETILE * ld;     // flxprec [ldp]
+    double *sFS = sFP + ETILE * ldp;    // flxsnow [ldp]
 
     for (int i = threadIdx.x; i <= COLPHYS_PLENEST; i += ENT) s_estbl[i] = estbl[i];
     tile_in(sT, io.t + col0 * L, nc, pver, ld);
@@ -401,10 +408,10 @@ int launch_zm_conv_evap(const ZmDev &P, const double *estbl_dev, int ncol, int p
                         const colphys_zm_conv_evap_io &io, hipStream_t st)
 {
     const int ld = (pver & 1) ? pver : pver + 1, ldp = ((pver + 1) & 1) ? pver + 1 : pver + 2;
-    const size_t lds = (size_t)TILE * (6 * ld + 2 * ldp) * sizeof(double);
+    const size_t lds = (size_t)ETILE * (6 * ld + 2 * ldp) * sizeof(double);
     if (lds > 150 * 1024) return COLPHYS_ERR_UNSUPPORTED;
     if (set_lds((const void *)zm_conv_evap_kernel, lds)) return COLPHYS_ERR_HIP;
-    const int nblk = (ncol + TILE - 1) / TILE;
+    const int nblk = (ncol + ETILE - 1) / ETILE;
     hipLaunchKernelGGL(zm_conv_evap_kernel, dim3(nblk), dim3(ENT), lds, st, P, estbl_dev, ncol, pver, deltat, io);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }

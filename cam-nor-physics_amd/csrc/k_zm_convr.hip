@@ -230,6 +230,9 @@ __device__ __forceinline__ double moist_static_energy_total(const ZmDev &P, doub
 //   s_tpv    : LDS, element for level k at s_tpv[k*WAVE]  (caller passes base + lane)
 //   s_mail   : LDS, MAIL_DOUBLES doubles for the block
 //   tp, qstp : optional 1-based outputs (parcel temperature / saturation mixing ratio), written where store_ok
+#ifndef CHAIN_WAVES_PER_SIMD
+#define CHAIN_WAVES_PER_SIMD 3
+#endif
 constexpr int MAIL_FIELDS = 4;
 constexpr int MAIL_DOUBLES = (2 * MAIL_FIELDS + 4) * WAVE;
 
@@ -1171,7 +1174,9 @@ __global__ __launch_bounds__(WAVE) void zm_plume1_kernel(ZmDev P, int ncol, int 
 // ------------------------------------------------------------------------------------------------------
 // Kernel 2b: second dilute ascent of the listed columns with that rate, re-trigger (:1080-1107)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(2 * WAVE) void zm_ascent2_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io, ZmWorkspace ws)
+// (register budget of three waves per SIMD, 168 VGPRs: beside the optics -- three waves of 168 -- a wave of this kernel
+// then fits as soon as ONE optics block retires from its SIMD; at 180 it needed two)
+__global__ __launch_bounds__(2 * WAVE, CHAIN_WAVES_PER_SIMD) void zm_ascent2_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io, ZmWorkspace ws)
 {
     CHAIN_PRIO();
     extern __shared__ double smem[];            // as zm_trigger_kernel
@@ -1197,7 +1202,7 @@ __global__ __launch_bounds__(2 * WAVE) void zm_ascent2_kernel(ZmDev P, int ncol,
 // ------------------------------------------------------------------------------------------------------
 // Kernel 2c: second ensemble pass, closure, tendencies, precipitation integrals of the re-triggered columns
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void zm_plume2_kernel(ZmDev P, int ncol, int pver, double delt, colphys_zm_convr_io io,
+__global__ __launch_bounds__(WAVE, CHAIN_WAVES_PER_SIMD) void zm_plume2_kernel(ZmDev P, int ncol, int pver, double delt, colphys_zm_convr_io io,
                                                         ZmWorkspace ws)
 {
     CHAIN_PRIO();
