@@ -32,6 +32,9 @@
 #ifndef AERO_SW_WAVES
 #define AERO_SW_WAVES 3                    // bands-outer SW kernel: waves per SIMD the register budget is set for
 #endif
+#ifndef AERO_LW_LDS_CAP_KB
+#define AERO_LW_LDS_CAP_KB 30              // LW: two band groups of 24 KB instead of one of 40 KB: 7 % slower alone, but four
+#endif                                    // blocks then leave 64 KB of a CU's LDS to the ZM chain running beside it (substep -1 %)
 #ifndef AERO_LDS_CAP_KB
 #define AERO_LDS_CAP_KB 53                 // three blocks per CU (A/B on MI355X: 53 KB x 3 beats 78 KB x 2)
 #endif
@@ -446,7 +449,7 @@ static int launch_aero(bool sw, const AeroDev &A, int ncol, int pver, const colp
     int ngroups = 1;
     for (;; ++ngroups) {
         const int bpg = (nb + ngroups - 1) / ngroups;
-        if ((2 * slice + (size_t)bpg * nout * NT) * sizeof(double) <= AERO_LDS_CAP_KB * 1024 || bpg == 1) break;
+        if ((2 * slice + (size_t)bpg * nout * NT) * sizeof(double) <= (size_t)(sw ? AERO_LDS_CAP_KB : AERO_LW_LDS_CAP_KB) * 1024 || bpg == 1) break;
     }
     const int bpg = (nb + ngroups - 1) / ngroups;
     ngroups = (nb + bpg - 1) / bpg;
