@@ -60,7 +60,10 @@ __device__ __forceinline__ void tile_out(double *g, const double *s, int nc, int
 #define GEO_TILE 32      // 17 KB of LDS per block at L32 (A/B 64 -> 32 columns: 0.031 -> 0.028 ms alone, substep -0.5 %)
 #endif
 constexpr int GT = GEO_TILE;  // columns per block
-constexpr int GNT = 256;      // threads per block: four waves move data (8 flat-index steps at L32), one wave scans
+#ifndef GEO_THREADS
+#define GEO_THREADS 128
+#endif
+constexpr int GNT = GEO_THREADS;   // threads per block: two waves move data (8 flat-index steps of a 32-column tile at L32), 32 lanes scan
 
 __global__ __launch_bounds__(GNT) void geopotential_kernel(int ncol, int pver, int dycore_kind, int nspecies,
                                                          const double *__restrict__ piln, const double *__restrict__ pint,
@@ -135,7 +138,10 @@ __global__ __launch_bounds__(GNT) void geopotential_kernel(int ncol, int pver, i
 // ------------------------------------------------------------------------------------------------------
 // zm_conv_evap (old_snow path; kemask = ke unless zm_org)
 // ------------------------------------------------------------------------------------------------------
-constexpr int ENT = 256;      // threads per block: four waves move the tiles (4 flat-index steps per tile at L32), 32 lanes scan
+#ifndef EVAP_THREADS
+#define EVAP_THREADS 256
+#endif
+constexpr int ENT = EVAP_THREADS;      // threads per block: four waves move the tiles (4 flat-index steps per tile at L32), 32 lanes scan
 __global__ __launch_bounds__(ENT) void zm_conv_evap_kernel(ZmDev P, const double *__restrict__ estbl, int ncol, int pver,
                                                          double deltat, colphys_zm_conv_evap_io io)
 {
