@@ -311,6 +311,23 @@ def test_chunk_entry_points_match_device_entry_points():
             assert np.array_equal(hout[k][c, 0, :lg], o[k][:lg]), k
 
 
+def test_no_column_convects():
+    """dry soundings: every chunk takes the reference's early return (lengath = 0, zm_conv.F90:917), outputs are the
+    initial zeros / defaults, and the second-ascent / plume launches find an empty list"""
+    from c_oracle import COracle
+    pver, ncol = 32, 700
+    params = cases.default_params(pver)
+    eng = engine(params)
+    co = COracle(params)
+    st = synth.make_state(ncol, pver, 91, rh_range=(0.05, 0.3))
+    args = cases.zm_args_from_state(st, st["zi"], st["zm"])
+    ref = co.zm_convr(*args)
+    assert ref["lengath"].sum() == 0
+    o = run_zm(eng, args)
+    check_zm(o, ref, ncol)
+    assert not o["heat"].any() and not o["prec"].any() and (o["jctop"] == pver).all() and (o["jcbot"] == 1).all()
+
+
 @pytest.mark.parametrize("ncol", [1, 5, 63, 64, 65, 257, 300])
 def test_ragged_column_counts_vs_c_oracle(ncol):
     """block tails of every kernel on the path: partial waves, partial column groups of the trigger's wave pairs, a

@@ -19,6 +19,8 @@ def rel_err_profile(a: np.ndarray, ref: np.ndarray) -> float:
     """max over columns of max_k|a-ref| / max_k|ref|; the last axis is the level axis"""
     a = np.asarray(a, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
     assert a.shape == ref.shape, (a.shape, ref.shape)
+    if a.size == 0:                      # e.g. the gathered set of a run in which no column convects
+        return 0.0
     if a.ndim == 1:
         scale = np.maximum(np.maximum(np.abs(a), np.abs(ref)), FLOOR * max(np.abs(ref).max(), 1e-300))
         return float((np.abs(a - ref) / scale).max()) if a.size else 0.0
