@@ -216,6 +216,36 @@ def test_modal_aero_vs_c_oracle(top_lev):
         assert sw["tauxar"][:, :, top_lev:].all()
 
 
+def test_modal_aero_edge_branches_vs_c_oracle():
+    """the optics' side branches: negative aerosol water (:841-844), particles beyond the size table in both directions
+    (:1559-1561 clamp, :875 large-particle extinction), refractive indices outside the table grid (table_interp
+    extrapolation below / clamp above), near-empty cells"""
+    from c_oracle import COracle
+    pver, ncol = 32, 400
+    params = cases.default_params(pver)
+    eng = engine(params)
+    co = COracle(params)
+    props = synth.make_aero_props(8)
+    st = synth.make_state(ncol, pver, 8)
+    aer = synth.make_aero_state(ncol, pver, props, 8)
+    rng = np.random.default_rng(8)
+    qw, dg, mm = aer["qaerwat"], aer["dgnumwet"], aer["specmmr"]
+    qw[:, ::7, :] *= -1.0                                        # negative water volume
+    qw[:, 3::11, :] *= 1.0e3                                     # water-dominated: index pulled to water's, off the grid
+    dg[:, 1::5, :] = 10.0 ** rng.uniform(-4.6, -3.5, dg[:, 1::5, :].shape)    # > 25 um surface-mode radius
+    dg[:, 2::9, :] = 10.0 ** rng.uniform(-9.5, -8.2, dg[:, 2::9, :].shape)    # < 0.01 um
+    mm[:, :, 4::13, :] *= 1.0e-8                                 # almost no dry aerosol
+    eng.aero_tables_set(props, synth.PHYSCONST)
+    co.aero_tables_set(props, synth.PHYSCONST)
+    d = eng.dev
+    a = (d(st["pdeldry"]), d(mm), d(dg), d(qw))
+    sw, sw_ref = to_np(eng.modal_aero_sw(*a)), co.modal_aero_sw(st, aer)
+    lw, lw_ref = to_np(eng.modal_aero_lw(*a)), co.modal_aero_lw(st, aer)
+    for k in ("tauxar", "wa", "ga", "fa"):
+        assert_close("modal_aero_sw." + k, sw[k], sw_ref[k])
+    assert_close("modal_aero_lw.tauxar", lw["tauxar"], lw_ref["tauxar"])
+
+
 # ---------------------------------------------------------------------------------------------------
 # (c) properties at BASELINE.json's full size
 # ---------------------------------------------------------------------------------------------------
