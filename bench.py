@@ -245,6 +245,14 @@ def main():
     side = side_saved
     torch.cuda.synchronize()
     prof = eng.profile()
+    # ... and once more with the two streams overlapping (eager launches): what the same kernels take while they share the GPU
+    prof_ov = None
+    if side is not None:
+        eng.profile_reset()
+        for _ in range(3):
+            substep()
+        torch.cuda.synchronize()
+        prof_ov = eng.profile()
     eng.profile_enable(False)
     ndeep = int(zm_out["lengath"].sum().item())
     status_bad = int((zm_out["status"] != 0).sum().item())
@@ -268,7 +276,13 @@ def main():
                     "kernel_ms": {k: round(v, 4) for k, v in kern_ms.items()},
                     "substep_bytes_per_column": substep_bytes(pver),
                     "substep_hbm_frac": round(substep_bytes(pver) * value / world / 1e9 / HBM_PEAK_GBS, 6),
-                    "note": "path is fp64-transcendental / latency bound, not HBM bound (SURVEY.md 0-4, 8d)"}
+                    "note": "path is fp64-transcendental / latency bound, not HBM bound (SURVEY.md 0-4, 8d)",
+                    "duration_source": "HIP events on the launch stream in a separate un-overlapped pass after the timed region; "
+                                       "rocprofv3 of `bench.py --serial --no-graph` averages the same launches "
+                                       "(profiles/r01_kernel_stats_serial.csv); the default command's rocprofv3 average "
+                                       "(profiles/r01_kernel_stats.csv) also contains the overlapped graph replays"}
+        if prof_ov is not None:
+            roofline["kernel_ms_overlapped"] = {k: round(v[0], 4) for k, v in prof_ov.items() if v[1] > 0}
         pm = pmc_of(dom) if (args.ncol == 48602 and pver == 32) else None
         if pm is not None:
             roofline["traffic"], roofline["traffic_source"] = pm["traffic"], pm["source"]
