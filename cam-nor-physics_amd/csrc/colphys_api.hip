@@ -697,6 +697,8 @@ struct Stager {
     Carver hc, dc;
     hipStream_t st = nullptr;
     hipEvent_t ev_pending = nullptr;
+    bool ok = true;                            // false once any copy / event call of this staging pass failed
+    void chk(hipError_t e) { if (e != hipSuccess) ok = false; }
     std::function<void()> scatter_pending;     // scatter of the previous download, run while the next one is in flight
     Stager(int nch, int pc, const int32_t *nc, void *hbase, void *dbase) : nchunks(nch), pcols(pc), ncol(nc), ncd(nch * pc), hc(hbase), dc(dbase) {}
     ~Stager()
@@ -707,8 +709,8 @@ struct Stager {
     void drain()
     {
         if (scatter_pending) {
-            hipEventSynchronize(ev_pending);
-            scatter_pending();
+            chk(hipEventSynchronize(ev_pending));
+            if (ok) scatter_pending();
             scatter_pending = nullptr;
         }
     }
@@ -731,7 +733,7 @@ struct Stager {
                     }
                 }
         });
-        hipMemcpyAsync(d, h, n * nf * sizeof(double), hipMemcpyHostToDevice, st);
+        chk(hipMemcpyAsync(d, h, n * nf * sizeof(double), hipMemcpyHostToDevice, st));
         return d;
     }
     int32_t *in_i(const int32_t *src, int nlev)
@@ -743,7 +745,7 @@ struct Stager {
                 for (int i = 0; i < pcols; ++i)
                     for (int k = 0; k < nlev; ++k) h[((size_t)c * pcols + i) * nlev + k] = src[(size_t)c * pcols * nlev + (size_t)k * pcols + i];
         });
-        hipMemcpyAsync(d, h, n * sizeof(int32_t), hipMemcpyHostToDevice, st);
+        chk(hipMemcpyAsync(d, h, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
         return d;
     }
     template <class T> T *out(int nlev) { return dc.take<T>((size_t)ncd * nlev); }
@@ -754,10 +756,10 @@ struct Stager {
     {
         const size_t n = (size_t)ncd * nlev;
         T *h = hc.take<T>(n);
-        hipMemcpyAsync(h, dev, n * sizeof(T), hipMemcpyDeviceToHost, st);
+        chk(hipMemcpyAsync(h, dev, n * sizeof(T), hipMemcpyDeviceToHost, st));
         drain();                                       // previous field: wait for ITS copy, scatter it
-        if (!ev_pending) hipEventCreateWithFlags(&ev_pending, hipEventDisableTiming);
-        hipEventRecord(ev_pending, st);
+        if (!ev_pending) chk(hipEventCreateWithFlags(&ev_pending, hipEventDisableTiming));
+        chk(hipEventRecord(ev_pending, st));
         Stager *self = this;
         scatter_pending = [self, dst, h, nlev, gathered, lengath]() {
             HostPool::get().run(self->nchunks, [&](int c0, int c1) {
@@ -818,7 +820,8 @@ int colphys_geopotential_t_chunks(int nchunks, int pcols, int pver, const int32_
     s.back(zi, d_zi, pverp, false, nullptr);
     s.back(zm, d_zm, pver, false, nullptr);
     (void)pmln;
-    return COLPHYS_OK;
+    s.drain();
+    return s.ok ? COLPHYS_OK : fail(COLPHYS_ERR_HIP, "a staging copy failed");
 }
 
 int colphys_zm_convr_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, double delt, const colphys_zm_convr_io *io)
@@ -875,7 +878,8 @@ int colphys_zm_convr_chunks(int nchunks, int pcols, int pver, const int32_t *nco
     s.back(io->jt, (const int32_t *)d.jt, 1, true, io->lengath);
     s.back(io->maxg, (const int32_t *)d.maxg, 1, true, io->lengath);
     s.back(io->ideep, (const int32_t *)d.ideep, 1, true, io->lengath);
-    return COLPHYS_OK;
+    s.drain();
+    return s.ok ? COLPHYS_OK : fail(COLPHYS_ERR_HIP, "a staging copy failed");
 }
 
 int colphys_zm_conv_evap_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, double deltat,
@@ -905,7 +909,8 @@ int colphys_zm_conv_evap_chunks(int nchunks, int pcols, int pver, const int32_t 
     s.back(io->flxsnow, (const double *)d.flxsnow, pverp, false, nullptr);
     s.back(io->prec, (const double *)d.prec, 1, false, nullptr);
     s.back(io->snow, (const double *)d.snow, 1, false, nullptr);
-    return COLPHYS_OK;
+    s.drain();
+    return s.ok ? COLPHYS_OK : fail(COLPHYS_ERR_HIP, "a staging copy failed");
 }
 
 int colphys_momtran_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, double dt, const colphys_momtran_io *io)
@@ -937,7 +942,8 @@ int colphys_momtran_chunks(int nchunks, int pcols, int pver, const int32_t *ncol
     for (int f = 0; f < 5; ++f)
         for (int m = 0; m < 2; ++m) s.back(h3[f] + (size_t)m * ncd * pver, (const double *)(o3[f] + (size_t)m * ncd * pver), pver, false, nullptr);
     s.back(io->seten, (const double *)d.seten, pver, false, nullptr);
-    return COLPHYS_OK;
+    s.drain();
+    return s.ok ? COLPHYS_OK : fail(COLPHYS_ERR_HIP, "a staging copy failed");
 }
 
 int colphys_convtran_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, int ncnst, double dt,
@@ -968,7 +974,8 @@ int colphys_convtran_chunks(int nchunks, int pcols, int pver, const int32_t *nco
     for (int m = 1; m < ncnst; ++m)
         if (io->doconvtran[m])
             s.back(io->dqdt + (size_t)m * ncd * pver, (const double *)(dq + (size_t)m * ncd * pver), pver, false, nullptr);
-    return COLPHYS_OK;
+    s.drain();
+    return s.ok ? COLPHYS_OK : fail(COLPHYS_ERR_HIP, "a staging copy failed");
 }
 
 static int aero_chunks(bool sw, int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io)
@@ -1013,7 +1020,8 @@ static int aero_chunks(bool sw, int nchunks, int pcols, int pver, const int32_t 
                             h[(((size_t)c * pcols + i) * nb + b) * nlevout + k];
     }
     s.back(io->status, (const int32_t *)d.status, 1, false, nullptr);
-    return COLPHYS_OK;
+    s.drain();
+    return s.ok ? COLPHYS_OK : fail(COLPHYS_ERR_HIP, "a staging copy failed");
 }
 int colphys_modal_aero_sw_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io) { return aero_chunks(true, nchunks, pcols, pver, ncol, io); }
 int colphys_modal_aero_lw_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io) { return aero_chunks(false, nchunks, pcols, pver, ncol, io); }
