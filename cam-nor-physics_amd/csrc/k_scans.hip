@@ -141,7 +141,11 @@ __global__ __launch_bounds__(GNT) void geopotential_kernel(int ncol, int pver, i
 #ifndef EVAP_THREADS
 #define EVAP_THREADS 256
 #endif
-constexpr int ENT = EVAP_THREADS;      // threads per block: four waves move the tiles (4 flat-index steps per tile at L32), 32 lanes scan
+constexpr int ENT = EVAP_THREADS;
+__device__ __forceinline__ double kemask_of(const ZmDev &P, double landfrac)
+{   // :1860-1866: ke, or the land/ocean blend when zm_org
+    return P.zm_org ? (P.ke * (1.0 - landfrac) + P.ke_lnd * landfrac) : P.ke;
+}      // threads per block: four waves move the tiles (4 flat-index steps per tile at L32), 32 lanes scan
 __global__ __launch_bounds__(ENT) void zm_conv_evap_kernel(ZmDev P, const double *__restrict__ estbl, int ncol, int pver,
                                                          double deltat, colphys_zm_conv_evap_io io)
 {
@@ -172,26 +176,24 @@ __global__ __launch_bounds__(ENT) void zm_conv_evap_kernel(ZmDev P, const double
     tile_in(sCL, io.cldfrc + col0 * L, nc, pver, ld);
     __syncthreads();
 
-    const int c = threadIdx.x;
-    if (c < nc) {
-        const int col = col0 + c;
-        const double tmelt = P.tmelt, gravit = P.gravit, latice = P.latice, latvap = P.latvap;
-        const double landfrac = io.landfrac[col];
-        const double prec = io.prec[col] * 1000.0;                               // :1797
-        double evpvint = 0.0, flxprec = 0.0, flxsnow = 0.0;
-        sFP[c * ldp] = 0.0;                                                      // :1812-1813
-        sFS[c * ldp] = 0.0;
-        for (int k = 0; k < pver; ++k) {
-            const double tk = sT[c * ld + k], pmid = sPM[c * ld + k], pdel = sPD[c * ld + k], qk = sQ[c * ld + k],
-                         prdprec = sPR[c * ld + k], cldfrc = sCL[c * ld + k];
-            // qsat: 1-K table with water<->ice transition (:1804; spec oracle/stubs/l0_arithmetic.F90)
-            double es, qs;
+    // Phase A, element-wise over the tile (all threads): everything of a level that does not depend on the fluxes coming
+    // down from above -- saturation (1-K table), the evaporation limit's flux-free factor, the snow fraction -- so that
+    // the serial top-down scan below is left with the recurrence itself.  Results replace t / q / cldfrc in their tiles:
+    //   sT  <- kemask*(1-cldfrc)*max(1 - q/(1+q)/qs, 0)   (the factor of sqrt(flxprec) in :1868, same operation order)
+    //   sQ  <- max(1 - q/(1+q)/qs, 0)                      (evplimit before the flux limiters, :1854)
+    //   sCL <- fsnow_conv, or -1 where t > tmelt            (cldfrc_fice :1809 and the melt test :1821)
+    {
+        const double tmelt = P.tmelt;
+        for (int i = threadIdx.x; i < nc * pver; i += ENT) {
+            const int cc = i / pver, k = i - cc * pver;
+            const double tk = sT[cc * ld + k], pmid = sPM[cc * ld + k], qk = sQ[cc * ld + k], cldfrc = sCL[cc * ld + k];
+            double es, qs;                                                       // qsat :1804 (spec oracle/stubs/l0_arithmetic.F90)
             {
                 const double t_tmp = fmax(fmin(tk, COLPHYS_TMAX_TBL) - COLPHYS_TMIN_TBL, 0.0);
-                const int i = (int)t_tmp + 1;
-                if (i < COLPHYS_PLENEST) {
+                const int it = (int)t_tmp + 1;
+                if (it < COLPHYS_PLENEST) {
                     const double weight = fmin(t_tmp - trunc(t_tmp), 1.0);
-                    es = (1.0 - weight) * s_estbl[i] + weight * s_estbl[i + 1];
+                    es = (1.0 - weight) * s_estbl[it] + weight * s_estbl[it + 1];
                 } else {
                     es = s_estbl[COLPHYS_PLENEST];
                 }
@@ -205,12 +207,31 @@ __global__ __launch_bounds__(ENT) void zm_conv_evap_kernel(ZmDev P, const double
                 else if (tk < tmin_fsnow) fsnow_conv = 1.0;
                 else fsnow_conv = (tmax_fsnow - tk) / (tmax_fsnow - tmin_fsnow);
             }
+            const double evplimit0 = fmax(1.0 - qk / (1.0 + qk) / qs, 0.0);      // :1854
+            sT[cc * ld + k] = kemask_of(P, io.landfrac[col0 + cc]) * (1.0 - cldfrc) * evplimit0;
+            sQ[cc * ld + k] = evplimit0;
+            sCL[cc * ld + k] = (tk > tmelt) ? -1.0 : fsnow_conv;
+        }
+    }
+    __syncthreads();
+
+    const int c = threadIdx.x;
+    if (c < nc) {
+        const int col = col0 + c;
+        const double gravit = P.gravit, latice = P.latice, latvap = P.latvap;
+        const double prec = io.prec[col] * 1000.0;                               // :1797
+        double evpvint = 0.0, flxprec = 0.0, flxsnow = 0.0;
+        sFP[c * ldp] = 0.0;                                                      // :1812-1813
+        sFS[c * ldp] = 0.0;
+        for (int k = 0; k < pver; ++k) {
+            const double kfac = sT[c * ld + k], pdel = sPD[c * ld + k], prdprec = sPR[c * ld + k], fs = sCL[c * ld + k];
+            const bool warm = fs < 0.0;
+            const double fsnow_conv = warm ? 0.0 : fs;
             double flxsntm, snowmlt;                                             // :1821-1828
-            if (tk > tmelt) { flxsntm = 0.0; snowmlt = flxsnow * gravit / pdel; }
+            if (warm) { flxsntm = 0.0; snowmlt = flxsnow * gravit / pdel; }
             else { flxsntm = flxsnow; snowmlt = 0.0; }
-            double evplimit = fmax(1.0 - qk / (1.0 + qk) / qs, 0.0);             // :1854
-            const double kemask = P.zm_org ? (P.ke * (1.0 - landfrac) + P.ke_lnd * landfrac) : P.ke;
-            double evpprec = kemask * (1.0 - cldfrc) * evplimit * sqrt(flxprec); // :1868
+            double evplimit = sQ[c * ld + k];                                    // :1854
+            double evpprec = kfac * sqrt(flxprec);                               // :1868
             evplimit = fmin(evplimit, flxprec * gravit / pdel);                  // :1885 (:1875-1878 disabled by tht_tweaks)
             evplimit = fmin(evplimit, (prec - evpvint) * gravit / pdel);         // :1888
             evpprec = fmin(evplimit, evpprec);
