@@ -555,7 +555,8 @@ __global__ __launch_bounds__(2 * TRIG_GROUPS_MAX * WAVE) void zm_trigger_kernel(
     const int col = bcol0 + group * WAVE + lane;
     const bool valid = col < ncol;
     const size_t L = (size_t)pver, LP = (size_t)pver + 1;
-    double *gmem = smem + (size_t)group * ((pver + 2) * WAVE + MAIL_DOUBLES);
+    const int rows = pver + 2 - (P.limcnv - 1);               // the profile is only touched at levels > msg = limcnv - 1
+    double *gmem = smem + (size_t)group * (rows * WAVE + MAIL_DOUBLES);
 
     // zero-fill every output of this block's columns, coalesced (:559-563, 625-650, 771-784 and the
     // gathered arrays, whose slots beyond lengath the reference leaves stale)
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(2 * TRIG_GROUPS_MAX * WAVE) void zm_trigger_kernel(
     const ColIn c = make_colin(P, io, valid ? col : ncol - 1, pver);
     const double pblt = pbl_top_index(c);
     BuoyRes r;
-    buoyan_dilute_2w<false, true>(P, c, pblt, -P.tentrm, 0.0, role, lane, gmem + lane, gmem + (pver + 2) * WAVE, nullptr,
+    buoyan_dilute_2w<false, true>(P, c, pblt, -P.tentrm, 0.0, role, lane, gmem + lane - (P.limcnv - 1) * WAVE, gmem + rows * WAVE, nullptr,
                                   nullptr, false, r);                                             // :544, 886
     if (role == 0 || !valid) return;
 
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(WAVE) void zm_trigger_fused_kernel(ZmDev P, int nco
     const ColIn c = make_colin(P, io, col, pver);
     const double pblt = pbl_top_index(c);
     BuoyRes r;
-    buoyan_dilute_2w<false, false>(P, c, pblt, -P.tentrm, 0.0, 1, lane, smem + lane, nullptr, nullptr, nullptr, false, r);   // :544, 886
+    buoyan_dilute_2w<false, false>(P, c, pblt, -P.tentrm, 0.0, 1, lane, smem + lane - (P.limcnv - 1) * WAVE, nullptr, nullptr, nullptr, false, r);   // :544, 886
 
     io.cape[col] = r.cape;
     io.status[col] = r.status;
@@ -1190,7 +1191,8 @@ __global__ __launch_bounds__(2 * WAVE, CHAIN_WAVES_PER_SIMD) void zm_ascent2_ker
     const ColIn c = make_colin(P, io, col, pver);
     const double pblt = pbl_top_index(c);
     BuoyRes r;
-    buoyan_dilute_2w<true, true>(P, c, pblt, ws.dmpdz2[col], ws.cin1[col], role, lane, smem + lane, smem + (pver + 2) * WAVE,
+    const int rows = pver + 2 - (P.limcnv - 1);
+    buoyan_dilute_2w<true, true>(P, c, pblt, ws.dmpdz2[col], ws.cin1[col], role, lane, smem + lane - (P.limcnv - 1) * WAVE, smem + rows * WAVE,
                            ws.tp2 + col * L - 1, ws.qstp2 + col * L - 1, valid, r);
     if (role == 0 || !valid) return;
     io.cape[col] = r.cape;
@@ -1397,7 +1399,7 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
 {
     if (pcols > 1024) return COLPHYS_ERR_ARG;
     const int nblk = (ncol + WAVE - 1) / WAVE;
-    const size_t lds = (size_t)(pver + 2) * WAVE * sizeof(double);
+    const size_t lds = (size_t)(pver + 2 - (P.limcnv - 1)) * WAVE * sizeof(double);   // parcel profile, levels above limcnv only
     const size_t lds2 = lds + MAIL_DOUBLES * sizeof(double);       // second ascent: two-wave pipeline with its mailbox
     const int nchunks = (ncol + pcols - 1) / pcols;
     if (hipMemsetAsync(ws.count, 0, sizeof(int), st) != hipSuccess) return COLPHYS_ERR_HIP;
@@ -1419,7 +1421,7 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
         if (atoi(e) == 2) paired = false;
     }
     int groups = TRIG_GROUPS_MAX;
-    while (groups > 1 && lds2 * groups > 150 * 1024) groups /= 2;
+    while (groups > 1 && lds2 * groups > 158 * 1024) groups /= 2;
     if (lds2 * groups > 160 * 1024) paired = false;
     if (paired) {
         const int ntrig = (ncol + groups * WAVE - 1) / (groups * WAVE);
