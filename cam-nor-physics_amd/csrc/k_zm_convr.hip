@@ -539,7 +539,7 @@ __device__ __forceinline__ void block_fill(double *p, size_t n, double v)
 // ne30 size there are only 760 column groups for 1 024 SIMDs, a second wave per group on ANOTHER SIMD would just
 // collide with other groups' waves, while on the SAME SIMD the pair fills each other's dependent-issue bubbles (a single
 // ascent wave keeps its SIMD 62 % busy) and the per-level latency drops to the longer sweep's.
-// (G < 4 when the per-group LDS does not allow four groups, e.g. L70: the pairs then sit on different SIMDs.)
+// (G < 4 when the per-group LDS does not allow four groups, e.g. beyond ~L75: the pairs then sit on different SIMDs.)
 #ifndef TRIG_GROUPS_MAX
 #define TRIG_GROUPS_MAX 4
 #endif
@@ -1405,7 +1405,8 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     if (hipMemsetAsync(ws.count, 0, sizeof(int), st) != hipSuccess) return COLPHYS_ERR_HIP;
     if (ev) hipEventRecord(ev[0], st);
     // trigger: wave pairs while the column groups alone leave SIMDs idle (four groups per block so that a pair shares a
-    // SIMD; fewer when the LDS profile is long, e.g. two at L70 -- still 9 % better in the overlapped substep there);
+    // SIMD; fewer when the LDS profile is long -- two pairs per block were still 9 % better than one wave per group in
+    // the overlapped substep at L70, before the profile was trimmed to the levels above limcnv and four fitted);
     // one wave per group doing both sweeps once the groups fill the SIMDs on their own (measured with the optics
     // running beside it: 48 602 columns 2.93 vs 3.01 ms, 97 202 columns 5.21 vs 5.26, 194 402 columns 10.24 vs 10.02,
     // 777 602 columns 41.7 vs 39.0).  COLPHYS_TRIG_MODE = 1 / 2 forces paired / fused (experiments).
