@@ -458,7 +458,8 @@ static int launch_aero(bool sw, const AeroDev &A, int ncol, int pver, const colp
     const dim3 grid((unsigned)((cells + NT - 1) / NT), (unsigned)ngroups);
     if (hipMemsetAsync(io.status, 0, sizeof(int32_t) * ncol, st) != hipSuccess) return COLPHYS_ERR_HIP;
 #ifndef AERO_SW_GROUPED
-    if (sw && A.nmodes <= NMMAX) {
+    const char *force_grouped = getenv("COLPHYS_SW_GROUPED");      // tests: the fallback for more than NMMAX modes
+    if (sw && A.nmodes <= NMMAX && !(force_grouped && atoi(force_grouped))) {
         const dim3 g1((unsigned)((cells + NT - 1) / NT));
         // LDS: the slice double buffer + the species volumes of all modes, [sum of nspec][NT] (nspec lives on the device:
         // size for the largest table the engine accepts would waste LDS, so the host mirror of nspec is used)

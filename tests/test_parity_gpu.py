@@ -109,8 +109,12 @@ def test_evap_and_momtran_vs_reference_golden(name):
     assert_close("convtran.dqdt", ct.cpu().numpy(), g["ct_dqdt"])
 
 
+@pytest.mark.parametrize("sw_kernel", ["bands-outer", "grouped"])
 @pytest.mark.parametrize("name", cases.AERO_GOLDEN)
-def test_modal_aero_vs_reference_golden(name):
+def test_modal_aero_vs_reference_golden(name, sw_kernel, monkeypatch):
+    """both SW kernels: bands-outer (up to four modes) and the grouped one that serves more modes (forced here)"""
+    if sw_kernel == "grouped":
+        monkeypatch.setenv("COLPHYS_SW_GROUPED", "1")
     g = cases.load_golden(name)
     pver = g["in_t"].shape[1]
     eng = engine(cases.default_params(pver))
