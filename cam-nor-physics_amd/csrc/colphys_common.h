@@ -123,14 +123,90 @@ __device__ __forceinline__ double cp_log10(double x)
     return dk * log10_2hi + (dk * log10_2lo + __builtin_fma(lm, ivln10_lo, lm * ivln10_hi));
 }
 
+// want_ln ? cp_log(x) : cp_log10(x), bit for bit, from ONE reduction + polynomial: the two lanes of a lane pair
+// (below) evaluate a natural and a decimal logarithm of different arguments in the same instruction stream.
+__device__ __forceinline__ double cp_log_sel(double x, bool want_ln)
+{
+    if (!(x > 0.0 && x < __builtin_inf())) return want_ln ? log(x) : log10(x);
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double ivln10_hi = 4.34294481903251816668e-01, ivln10_lo = 1.09831965021676507e-17;
+    const double log10_2hi = 0.3010299955494702, log10_2lo = 1.1451100898021838e-10;
+    const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
+                 L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+                 L7 = 1.479819860511658591e-01;
+    int k = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, L6, L4), L2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, L7, L5), L3), L1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double sR = s * (hfsq + R);
+    const double ln = dk * ln2_hi - ((hfsq - (sR + dk * ln2_lo)) - f);                    // cp_log's tail
+    const double lm = f - (hfsq - sR);                                                     // cp_log_core's
+    const double l10 = dk * log10_2hi + (dk * log10_2lo + __builtin_fma(lm, ivln10_lo, lm * ivln10_hi));   // cp_log10's tail
+    return want_ln ? ln : l10;
+}
+
+// ---- lane pairs -----------------------------------------------------------------------------------------
+// The dilute-parcel ascent is one long dependent chain per column (a lone wave retires one dependent fp64
+// instruction per ~8.6 cycles, scripts/ubench), and most of it is the saturation-pressure / entropy evaluation inside
+// Brent's iteration: 3 exp10 + 3 logarithms of which two exp10 and two logarithms are mutually independent.  With
+// LPC = 2 a column owns TWO adjacent lanes that hold bit-identical state and run the same instruction stream; inside an
+// evaluation the odd lane ("half") takes the second member of each independent pair and the values are exchanged by DPP
+// (quad_perm [1,0,3,2]: no LDS, no exec change).  Every value is produced by the same operations in the same order as
+// with one lane per column, so results are bit-identical by construction; the chain per evaluation is ~0.62x as long.
+__device__ __forceinline__ double pair_swap(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
 // ---- saturation vapour pressure: Goff-Gratch over water / ice (spec: oracle/stubs/l0_arithmetic.F90) ----
+// u = Tboil/T and v = T/Tboil as the caller formed them (quotients in svp_water_gg, products with a shared
+// reciprocal inside Brent's function evaluation).  WANT_LN: also return lnval = cp_log(lnarg) (the entropy's
+// log(T/Tfreez), which a lane pair evaluates beside log10(u)).
+template <int LPC, bool WANT_LN>
+__device__ __forceinline__ double svp_gg_core(double u, double v, bool half, double lnarg, double &lnval)
+{
+    const double um1 = u - 1.0;
+    double l10u, e2, e3;
+    if (LPC == 2) {
+        if (WANT_LN) {
+            const double lg = cp_log_sel(half ? lnarg : u, half);
+            const double lgo = pair_swap(lg);
+            l10u = half ? lgo : lg;
+            lnval = half ? lg : lgo;
+        } else {
+            l10u = cp_log10(u);
+        }
+        const double ee = exp10(half ? -3.49149 * um1 : 11.344 * (1.0 - v));
+        const double eo = pair_swap(ee);
+        e2 = half ? eo : ee;
+        e3 = half ? ee : eo;
+    } else {
+        l10u = cp_log10(u);
+        if (WANT_LN) lnval = cp_log(lnarg);
+        e2 = exp10(11.344 * (1.0 - v));
+        e3 = exp10(-3.49149 * um1);
+    }
+    return exp10(-7.90298 * um1 + 5.02808 * l10u - 1.3816e-7 * (e2 - 1.0) + 8.1328e-3 * (e3 - 1.0)
+                 + 3.0057148979490314) * 100.0;        // log10(1013.246), correctly rounded
+}
 __device__ inline double svp_water_gg(double t)
 {
     const double tboil = 373.16;
-    return exp10(-7.90298 * (tboil / t - 1.0) + 5.02808 * cp_log10(tboil / t)
-                 - 1.3816e-7 * (exp10(11.344 * (1.0 - t / tboil)) - 1.0)
-                 + 8.1328e-3 * (exp10(-3.49149 * (tboil / t - 1.0)) - 1.0)
-                 + 3.0057148979490314) * 100.0;        // log10(1013.246), correctly rounded
+    double unused;
+    return svp_gg_core<1, false>(tboil / t, t / tboil, false, 0.0, unused);
 }
 
 // ---- launchers implemented in the k_*.hip files ------------------------------------------------------

@@ -36,33 +36,53 @@ namespace {
 // ------------------------------------------------------------------------------------------------------
 // L0 seams (spec: oracle/stubs/l0_arithmetic.F90)
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void qsat_hPa(const ZmDev &P, double t, double p_hPa, double &es_hPa, double &qs)
-{   // qsat_hPa :5421-5437 around qsat_water(t, p[Pa])
+// LPC / half: lane pairs (colphys_common.h); LPC = 1 is one lane per column, half is then false.
+template <int LPC = 1>
+__device__ __forceinline__ void qsat_from_es(const ZmDev &P, double es, double p_hPa, double &es_hPa, double &qs)
+{   // qsat_hPa :5421-5437 around qsat_water(t, p[Pa]), given es = svp_water(t) [Pa]
     const double p = p_hPa * 100.0;
-    double es = svp_water_gg(t);
     if ((p - es) <= 0.0) qs = 1.0;
     else qs = P.epsilo * es / (p - P.omeps * es);
     es = fmin(es, p);
     es_hPa = es * 0.01;
 }
+template <int LPC = 1>
+__device__ __forceinline__ void qsat_hPa(const ZmDev &P, double t, double p_hPa, double &es_hPa, double &qs, bool half = false)
+{
+    double unused;
+    const double es = svp_gg_core<LPC, false>(373.16 / t, t / 373.16, half, 0.0, unused);
+    qsat_from_es(P, es, p_hPa, es_hPa, qs);
+}
 
-__device__ __forceinline__ double entropy_d(const ZmDev &P, double TK, double p, double qtot)
+template <int LPC = 1>
+__device__ __forceinline__ double entropy_d(const ZmDev &P, double TK, double p, double qtot, bool half = false)
 {   // :5280-5300
     const double pref = 1000.0;
     double L = P.rl - (P.cpliq - P.cpwv) * (TK - P.tfreez);
-    double est, qst;
-    qsat_hPa(P, TK, p, est, qst);
+    double est, qst, lnT;
+    const double es = svp_gg_core<LPC, true>(373.16 / TK, TK / 373.16, half, TK / P.tfreez, lnT);
+    qsat_from_es(P, es, p, est, qst);
     double qv = fmin(qtot, qst);
     double e = qv * p / (P.eps1 + qv);
-    return (P.cpres + qtot * P.cpliq) * cp_log(TK / P.tfreez) - P.rgas * cp_log((p - e) / pref) + L * qv / TK
-           - qv * P.rh2o * cp_log(qv / qst);
+    double lgp, lgq;
+    if (LPC == 2) {                         // the pair splits log((p - e)/pref) and log(qv/qst)
+        const double lg = cp_log((half ? qv : (p - e)) / (half ? qst : pref));
+        const double lgo = pair_swap(lg);
+        lgp = half ? lgo : lg;
+        lgq = half ? lg : lgo;
+    } else {
+        lgp = cp_log((p - e) / pref);
+        lgq = cp_log(qv / qst);
+    }
+    return (P.cpres + qtot * P.cpliq) * lnT - P.rgas * lgp + L * qv / TK - qv * P.rh2o * lgq;
 }
 
-__device__ __forceinline__ double enthalpy_d(const ZmDev &P, double TK, double p, double qtot, double z)
+template <int LPC = 1>
+__device__ __forceinline__ double enthalpy_d(const ZmDev &P, double TK, double p, double qtot, double z, bool half = false)
 {   // :5440-5457
     double L = P.rl - (P.cpliq - P.cpwv) * (TK - P.tfreez);
     double est, qst;
-    qsat_hPa(P, TK, p, est, qst);
+    qsat_hPa<LPC>(P, TK, p, est, qst, half);
     double qv = fmin(qtot, qst);
     return (P.cpres + qtot * P.cpliq) * TK + L * qv + (1.0 + qtot) * P.grav * z;
 }
@@ -86,9 +106,10 @@ __device__ __forceinline__ double enthalpy_d(const ZmDev &P, double TK, double p
 #ifndef BRENT_INLINE
 #define BRENT_INLINE __forceinline__
 #endif
-template <int KIND>
+//  (5) LPC = 2: the function evaluation runs on a lane pair (colphys_common.h): same values, shorter chain.
+template <int KIND, int LPC = 1>
 __device__ BRENT_INLINE int invert_brent(const ZmDev &P, double s, double p, double z, double qt, double &T, double &qst,
-                                         double Tfg)
+                                         double Tfg, bool half = false)
 {
     const int LOOPMAX = 100;
     const double EPS = 3.e-8;
@@ -108,12 +129,10 @@ __device__ BRENT_INLINE int invert_brent(const ZmDev &P, double s, double p, dou
 
     auto feval = [&](double TK, double &qs_out) -> double {
         const double rt = 1.0 / TK;
-        // Goff-Gratch over water (svp_water_gg, colphys_common.h) on the shared 1/T
-        const double u = 373.16 * rt;
-        const double es = exp10(-7.90298 * (u - 1.0) + 5.02808 * cp_log10(u)
-                                - 1.3816e-7 * (exp10(11.344 * (1.0 - TK * RTBOIL)) - 1.0)
-                                + 8.1328e-3 * (exp10(-3.49149 * (u - 1.0)) - 1.0)
-                                + 3.0057148979490314) * 100.0;
+        // Goff-Gratch over water (svp_gg_core, colphys_common.h) on the shared 1/T; the entropy's log(T/Tfreez) rides
+        // beside its log10 on the second lane of a pair
+        double lnT = 0.0;
+        const double es = svp_gg_core<LPC, KIND == 0>(373.16 * rt, TK * RTBOIL, half, TK * rtfreez, lnT);
         double qs;                             // qsat_water: qs = eps es / (p - (1-eps) es), 1 where p <= es
         if ((pPa - es) <= 0.0) qs = 1.0;
         else qs = P.epsilo * es / (pPa - P.omeps * es);
@@ -130,7 +149,7 @@ __device__ BRENT_INLINE int invert_brent(const ZmDev &P, double s, double p, dou
             lgp = cp_log((p - e) * 0.001);
             lgq = 0.0;                         // log(qs/qs)
         }
-        return ((P.cpres + qt * P.cpliq) * cp_log(TK * rtfreez) - P.rgas * lgp + L * qv * rt - qv * P.rh2o * lgq) - s;   // :5297
+        return ((P.cpres + qt * P.cpliq) * lnT - P.rgas * lgp + L * qv * rt - qv * P.rh2o * lgq) - s;   // :5297
     };
 
     a = Tfg - 10;
@@ -233,15 +252,31 @@ __device__ __forceinline__ double moist_static_energy_total(const ZmDev &P, doub
 #ifndef CHAIN_WAVES_PER_SIMD
 #define CHAIN_WAVES_PER_SIMD 3
 #endif
+// Issue priority inside a wave pair.  The two waves of a pair share a SIMD (trigger) and VALU issue is arbitrated by
+// priority, then age (MI355X_MICROARCH.md, "Two waves per SIMD"): wave B carries 2/3 of the work and is the pair's
+// critical path, wave A (the OLDER wave of the block, which would win every tie) only has to stay one level ahead.
+// s_setprio ignores EXEC, so the role test must be wave-uniform by construction (readfirstlane).
+#ifndef PIPE_PRIO_A
+#define PIPE_PRIO_A 1
+#endif
+#ifndef PIPE_PRIO_B
+#define PIPE_PRIO_B 3
+#endif
+#define PIPE_PRIO(role)                                                                   \
+    do {                                                                                  \
+        if (__builtin_amdgcn_readfirstlane(role) == 0) __builtin_amdgcn_s_setprio(PIPE_PRIO_A); \
+        else __builtin_amdgcn_s_setprio(PIPE_PRIO_B);                                     \
+    } while (0)
 constexpr int MAIL_FIELDS = 4;
 constexpr int MAIL_DOUBLES = (2 * MAIL_FIELDS + 4) * WAVE;
 
-template <bool STORE_TP, bool PIPE>
+template <bool STORE_TP, bool PIPE, int LPC>
 __device__ void buoyan_dilute_2w(const ZmDev &P, const ColIn &c, double pblt, double dmpdz, double cin_in, int role, int lane,
                                  double *s_tpv, double *s_mail, double *tp, double *qstp, bool store_ok, BuoyRes &r)
 {
     const int pver = c.pver, msg = c.msg;
     const int npblt = (int)lrint(pblt);
+    const bool half = (LPC == 2) && (lane & 1);          // second lane of this column's pair (colphys_common.h)
     const double lwmax = 1.e-3, tscool = 0.0;
     double hmax = 0.0, pl, ql;
     int status = 0;
@@ -306,16 +341,16 @@ __device__ void buoyan_dilute_2w(const ZmDev &P, const ColIn &c, double pblt, do
         double est;
         if (P.lparcel_pbl) {
             qtp0 = ql;
-            sp0 = enthalpy_d(P, r.tl, pl, qtp0, zl);
+            sp0 = enthalpy_d<LPC>(P, r.tl, pl, qtp0, zl, half);
         } else {
             qtp0 = qk;
-            sp0 = enthalpy_d(P, tk, pk, qtp0, zk);
+            sp0 = enthalpy_d<LPC>(P, tk, pk, qtp0, zk, half);
         }
         mp0 = 1.0;
         smix1_kp1 = sp0;
         qtmix_kp1 = qtp0;
         tmix1_kp1 = tk;
-        qsat_hPa(P, tmix1_kp1, pk, est, qsmix1_kp1);
+        qsat_hPa<LPC>(P, tmix1_kp1, pk, est, qsmix1_kp1, half);
         t_kp1 = tk; q_kp1 = qk; p_kp1 = pk; z_kp1 = zk;
         // the four input values of the NEXT level are requested one level ahead: their (strided, usually L2-missing)
         // loads complete under the Brent solves
@@ -331,7 +366,7 @@ __device__ void buoyan_dilute_2w(const ZmDev &P, const ColIn &c, double pblt, do
         const double tenv = 0.5 * (tk + t_kp1);
         const double penv = 0.5 * (pk + p_kp1);
         const double zenv = 0.5 * (zk + z_kp1);
-        const double senv = enthalpy_d(P, tenv, penv, qtenv, zenv);
+        const double senv = enthalpy_d<LPC>(P, tenv, penv, qtenv, zenv, half);
         const double dpdz = -(penv * P.grav) / (P.rgas * tenv);
         const double dzdp = 1.0 / dpdz;
         const double dmpdp = dmpdz * dzdp;
@@ -340,7 +375,7 @@ __device__ void buoyan_dilute_2w(const ZmDev &P, const ColIn &c, double pblt, do
         mp = mp - dmpdp * dp;
         const double smix1 = (sp0 + sp) / (mp0 + mp);
         qtmix = (qtp0 + qtp) / (mp0 + mp);
-        status |= invert_brent<1>(P, smix1, pk, zk, qtmix, tmix, qsmix, tmix1_kp1);
+        status |= invert_brent<1, LPC>(P, smix1, pk, zk, qtmix, tmix, qsmix, tmix1_kp1, half);
 
         if (qsmix <= qtmix && qsmix1_kp1 > qtmix_kp1) {             // LCL :5111-5133
             r.lcl = k;
@@ -354,11 +389,11 @@ __device__ void buoyan_dilute_2w(const ZmDev &P, const ColIn &c, double pblt, do
             const double slcl = smix1_kp1 + dsdp * (pl - p_kp1);
             const double qtlcl = qtmix_kp1 + dqtdp * (pl - p_kp1);
             double qslcl;
-            status |= invert_brent<1>(P, slcl, pl, zl, qtlcl, r.tl, qslcl, tmix);
+            status |= invert_brent<1, LPC>(P, slcl, pl, zl, qtlcl, r.tl, qslcl, tmix, half);
         }
         tmix1_kp1 = tmix; qsmix1_kp1 = qsmix; qtmix_kp1 = qtmix; smix1_kp1 = smix1;
         t_kp1 = tk; q_kp1 = qk; p_kp1 = pk; z_kp1 = zk;
-        smix2 = entropy_d(P, tmix, pk, qtmix);                      // :5204, what sweep 2 starts from
+        smix2 = entropy_d<LPC>(P, tmix, pk, qtmix, half);                      // :5204, what sweep 2 starts from
     };
 
     // ---- sweep 2 (:5175-5273): state and one level ------------------------------------------------------------
@@ -367,7 +402,7 @@ __device__ void buoyan_dilute_2w(const ZmDev &P, const ColIn &c, double pblt, do
         const int k = klaunch;                                      // :5180-5200
         const double tk = c.T(k), qk = c.Q(k), pk = c.Pm(k);
         double est;
-        qsat_hPa(P, tk, pk, est, qsmix2_kp1);
+        qsat_hPa<LPC>(P, tk, pk, est, qsmix2_kp1, half);
         const double tpk = tk, qstpk = qk;
         s_tpv[k * WAVE] = (tpk + c.tpert) * (1.0 + qstpk / P.eps1) / (1.0 + qstpk);   // :5194
         if (STORE_TP && store_ok) { tp[k] = tpk; qstp[k] = qstpk; }
@@ -385,7 +420,7 @@ __device__ void buoyan_dilute_2w(const ZmDev &P, const ColIn &c, double pblt, do
             new_s = smix2 + ds_xsh2o + ds_freeze;
             new_q = qtmix - xsh2o;
             const double tfguess = tmix;
-            status |= invert_brent<0>(P, new_s, pk, 0.0, new_q, tmix, qsmix, tfguess);
+            status |= invert_brent<0, LPC>(P, new_s, pk, 0.0, new_q, tmix, qsmix, tfguess, half);
         }
         xsh2o_kp1 = xsh2o; ds_xsh2o_kp1 = ds_xsh2o; ds_freeze_kp1 = ds_freeze; qsmix2_kp1 = qsmix;
 
@@ -543,17 +578,21 @@ __device__ __forceinline__ void block_fill(double *p, size_t n, double v)
 #ifndef TRIG_GROUPS_MAX
 #define TRIG_GROUPS_MAX 4
 #endif
+// LPC = 2: a column owns a lane pair (colphys_common.h), a wave serves 32 columns: twice the waves, each ~0.6x as long.
+template <int LPC>
 __global__ __launch_bounds__(2 * TRIG_GROUPS_MAX * WAVE) void zm_trigger_kernel(ZmDev P, int ncol, int pver, int TRIG_GROUPS,
                                                                                colphys_zm_convr_io io, ZmWorkspace ws)
 {
-    CHAIN_PRIO();
+    constexpr int CPW = WAVE / LPC;             // columns per wave
     extern __shared__ double smem[];            // per group: [(pver+2)][WAVE] parcel virtual temperature / buoyancy + mailbox
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
     const int role = wave / TRIG_GROUPS, group = wave % TRIG_GROUPS;
-    const int bcol0 = blockIdx.x * TRIG_GROUPS * WAVE;
-    const int bnb = min(TRIG_GROUPS * WAVE, ncol - bcol0);          // columns of this block
-    const int col = bcol0 + group * WAVE + lane;
+    PIPE_PRIO(role);
+    const int bcol0 = blockIdx.x * TRIG_GROUPS * CPW;
+    const int bnb = min(TRIG_GROUPS * CPW, ncol - bcol0);           // columns of this block
+    const int col = bcol0 + group * CPW + lane / LPC;
     const bool valid = col < ncol;
+    const bool first = (LPC == 1) || !(lane & 1);                   // the lane of a pair that stores the column's results
     const size_t L = (size_t)pver, LP = (size_t)pver + 1;
     const int rows = pver + 2 - (P.limcnv - 1);               // the profile is only touched at levels > msg = limcnv - 1
     double *gmem = smem + (size_t)group * (rows * WAVE + MAIL_DOUBLES);
@@ -567,7 +606,7 @@ __global__ __launch_bounds__(2 * TRIG_GROUPS_MAX * WAVE) void zm_trigger_kernel(
         block_fill(io.mcon + bcol0 * LP, bnb * LP, 0.0);
         block_fill(io.pflx + bcol0 * LP, bnb * LP, 0.0);
     }
-    if (role == 1 && valid) {
+    if (role == 1 && valid && first) {
         io.prec[col] = 0.0; io.rliq[col] = 0.0; io.rice[col] = 0.0;
         io.jctop[col] = pver; io.jcbot[col] = 1;
         io.dsubcld[col] = 0.0; io.jt[col] = 0; io.maxg[col] = 0; io.ideep[col] = 0;
@@ -578,9 +617,9 @@ __global__ __launch_bounds__(2 * TRIG_GROUPS_MAX * WAVE) void zm_trigger_kernel(
     const ColIn c = make_colin(P, io, valid ? col : ncol - 1, pver);
     const double pblt = pbl_top_index(c);
     BuoyRes r;
-    buoyan_dilute_2w<false, true>(P, c, pblt, -P.tentrm, 0.0, role, lane, gmem + lane - (P.limcnv - 1) * WAVE, gmem + rows * WAVE, nullptr,
-                                  nullptr, false, r);                                             // :544, 886
-    if (role == 0 || !valid) return;
+    buoyan_dilute_2w<false, true, LPC>(P, c, pblt, -P.tentrm, 0.0, role, lane, gmem + lane - (P.limcnv - 1) * WAVE, gmem + rows * WAVE, nullptr,
+                                       nullptr, false, r);                                        // :544, 886
+    if (role == 0 || !valid || !first) return;
 
     io.cape[col] = r.cape;
     io.status[col] = r.status;
@@ -621,7 +660,7 @@ __global__ __launch_bounds__(WAVE) void zm_trigger_fused_kernel(ZmDev P, int nco
     const ColIn c = make_colin(P, io, col, pver);
     const double pblt = pbl_top_index(c);
     BuoyRes r;
-    buoyan_dilute_2w<false, false>(P, c, pblt, -P.tentrm, 0.0, 1, lane, smem + lane - (P.limcnv - 1) * WAVE, nullptr, nullptr, nullptr, false, r);   // :544, 886
+    buoyan_dilute_2w<false, false, 1>(P, c, pblt, -P.tentrm, 0.0, 1, lane, smem + lane - (P.limcnv - 1) * WAVE, nullptr, nullptr, nullptr, false, r);   // :544, 886
 
     io.cape[col] = r.cape;
     io.status[col] = r.status;
@@ -1177,24 +1216,27 @@ __global__ __launch_bounds__(WAVE) void zm_plume1_kernel(ZmDev P, int ncol, int 
 // ------------------------------------------------------------------------------------------------------
 // (register budget of three waves per SIMD, 168 VGPRs: beside the optics -- three waves of 168 -- a wave of this kernel
 // then fits as soon as ONE optics block retires from its SIMD; at 180 it needed two)
+template <int LPC>
 __global__ __launch_bounds__(2 * WAVE, CHAIN_WAVES_PER_SIMD) void zm_ascent2_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io, ZmWorkspace ws)
 {
-    CHAIN_PRIO();
+    constexpr int CPW = WAVE / LPC;             // listed columns per wave pair
     extern __shared__ double smem[];            // as zm_trigger_kernel
     const int lane = threadIdx.x & (WAVE - 1), role = threadIdx.x >> 6;
+    PIPE_PRIO(role);
     const int count = *ws.count;
-    if ((int)blockIdx.x * WAVE >= count) return;                  // block-uniform
-    const int gid = blockIdx.x * WAVE + lane;
+    if ((int)blockIdx.x * CPW >= count) return;                   // block-uniform
+    const int gid = blockIdx.x * CPW + lane / LPC;
     const bool valid = gid < count;
+    const bool first = (LPC == 1) || !(lane & 1);
     const int col = ws.list[valid ? gid : count - 1];             // lanes past the list shadow its last column
     const size_t L = (size_t)pver;
     const ColIn c = make_colin(P, io, col, pver);
     const double pblt = pbl_top_index(c);
     BuoyRes r;
     const int rows = pver + 2 - (P.limcnv - 1);
-    buoyan_dilute_2w<true, true>(P, c, pblt, ws.dmpdz2[col], ws.cin1[col], role, lane, smem + lane - (P.limcnv - 1) * WAVE, smem + rows * WAVE,
-                           ws.tp2 + col * L - 1, ws.qstp2 + col * L - 1, valid, r);
-    if (role == 0 || !valid) return;
+    buoyan_dilute_2w<true, true, LPC>(P, c, pblt, ws.dmpdz2[col], ws.cin1[col], role, lane, smem + lane - (P.limcnv - 1) * WAVE, smem + rows * WAVE,
+                                      ws.tp2 + col * L - 1, ws.qstp2 + col * L - 1, valid && first, r);
+    if (role == 0 || !valid || !first) return;
     io.cape[col] = r.cape;
     io.status[col] |= r.status;
     ws.cape2[col] = r.cape; ws.tl2[col] = r.tl; ws.lcl2[col] = r.lcl; ws.lel2[col] = r.lel; ws.mx2[col] = r.mx;
@@ -1421,14 +1463,34 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
         if (atoi(e) == 1) paired = true;
         if (atoi(e) == 2) paired = false;
     }
+    // lane pairs (two lanes per column, colphys_common.h): the second ascent always (it covers the ~10 % triggered
+    // columns, the SIMDs are empty: 0.57 -> 0.49 ms); not the trigger, whose 1 520 waves already keep two dependent
+    // chains on every SIMD -- twice the waves at 0.8x the length each is 1.03 ms against 0.76 (measured, 48 602 columns).
+    // COLPHYS_LPC_TRIG / COLPHYS_LPC_ASC = 1 / 2 force the choice (experiments).
+    static int lpc_trig_env = -1, lpc_asc_env = -1;
+    if (lpc_trig_env < 0) {
+        const char *e = getenv("COLPHYS_LPC_TRIG");
+        lpc_trig_env = e ? atoi(e) : 0;
+        e = getenv("COLPHYS_LPC_ASC");
+        lpc_asc_env = e ? atoi(e) : 0;
+    }
+    const int nblk32 = (ncol + 31) / 32;
+    int lpc_trig = 1;
+    if (lpc_trig_env == 1 || lpc_trig_env == 2) lpc_trig = lpc_trig_env;
+    int lpc_asc = 2;
+    if (lpc_asc_env == 1 || lpc_asc_env == 2) lpc_asc = lpc_asc_env;
     int groups = TRIG_GROUPS_MAX;
+    if (lpc_trig == 2) groups = 2;              // blocks of two pairs: three of them share a CU at three waves per SIMD
     while (groups > 1 && lds2 * groups > 158 * 1024) groups /= 2;
     if (lds2 * groups > 160 * 1024) paired = false;
     if (paired) {
-        const int ntrig = (ncol + groups * WAVE - 1) / (groups * WAVE);
+        const int cpb = groups * (WAVE / lpc_trig);
+        const int ntrig = (ncol + cpb - 1) / cpb;
         const size_t ldst = lds2 * groups;
-        if (ldst > 64 * 1024) hipFuncSetAttribute((const void *)zm_trigger_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);
-        hipLaunchKernelGGL(zm_trigger_kernel, dim3(ntrig), dim3(2 * groups * WAVE), ldst, st, P, ncol, pver, groups, io, ws);
+        const void *fn = lpc_trig == 2 ? (const void *)zm_trigger_kernel<2> : (const void *)zm_trigger_kernel<1>;
+        if (ldst > 64 * 1024) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);
+        if (lpc_trig == 2) hipLaunchKernelGGL(zm_trigger_kernel<2>, dim3(ntrig), dim3(2 * groups * WAVE), ldst, st, P, ncol, pver, groups, io, ws);
+        else hipLaunchKernelGGL(zm_trigger_kernel<1>, dim3(ntrig), dim3(2 * groups * WAVE), ldst, st, P, ncol, pver, groups, io, ws);
     } else {
         if (lds > 160 * 1024) return COLPHYS_ERR_UNSUPPORTED;
         if (lds > 64 * 1024) hipFuncSetAttribute((const void *)zm_trigger_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1439,8 +1501,13 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     const int nper = ncol < 256 * 12 ? ncol : 256 * 12;       // persistent: ~12 waves per CU fit in LDS at L32
     hipLaunchKernelGGL(zm_plume1_kernel, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, io, ws);
     if (ev) { hipEventRecord(ev[3], st); hipEventRecord(ev[4], st); }
-    if (lds2 > 64 * 1024) hipFuncSetAttribute((const void *)zm_ascent2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipLaunchKernelGGL(zm_ascent2_kernel, dim3(nblk), dim3(2 * WAVE), lds2, st, P, ncol, pver, io, ws);
+    if (lpc_asc == 2) {
+        if (lds2 > 64 * 1024) hipFuncSetAttribute((const void *)zm_ascent2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        hipLaunchKernelGGL(zm_ascent2_kernel<2>, dim3(nblk32), dim3(2 * WAVE), lds2, st, P, ncol, pver, io, ws);
+    } else {
+        if (lds2 > 64 * 1024) hipFuncSetAttribute((const void *)zm_ascent2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        hipLaunchKernelGGL(zm_ascent2_kernel<1>, dim3(nblk), dim3(2 * WAVE), lds2, st, P, ncol, pver, io, ws);
+    }
     if (ev) { hipEventRecord(ev[5], st); hipEventRecord(ev[6], st); }
     hipLaunchKernelGGL(zm_plume2_kernel, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, delt, io, ws);
     ZmTendDiag dg{};
