@@ -106,6 +106,14 @@ class ConvtranIO(C.Structure):
     )
 
 
+class ZmConvTend2IO(C.Structure):
+    _fields_ = (
+        [(n, PD) for n in ("q", "fracis", "pdeldry", "mu", "md", "du", "eu", "ed", "dp")]
+        + [(n, PI) for n in ("jt", "maxg", "ideep", "lq", "isdry")]
+        + [("ptend_q", PD)]
+    )
+
+
 # zm_conv_tend on resident data (colphys_zm_conv_tend_io): name -> (kind, levels); kind "d" double, "i" int32; levels 0 = [ncol],
 # 1 = [ncol][pver], 2 = [ncol][pver+1], 3 = [nchunks]
 ZM_TEND_IN = ("t", "q", "u", "v", "pmid", "pint", "pdel", "rpdel", "lnpint", "lnpmid", "zm", "zi", "phis", "ps", "rair", "zvir",

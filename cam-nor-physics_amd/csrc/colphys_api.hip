@@ -61,6 +61,7 @@ Arena g_ws_arena;        // ZmWorkspace
 Arena g_dev_arena;       // device staging for *_chunks
 Arena g_pin_arena;       // pinned host staging for *_chunks
 Arena g_tend_arena;      // work arrays of colphys_zm_conv_tend_dev
+Arena g_ct_arena;        // convtran: gathered-row list, its count, il2g per chunk
 
 // carve helper
 struct Carver {
@@ -250,7 +251,7 @@ int colphys_finalize(void)
         for (void *b : g_aero_bufs) hipFree(b);
         g_aero_bufs.clear();
         g_aero_set = false;
-        g_ws_arena.release(); g_dev_arena.release(); g_pin_arena.release(); g_tend_arena.release();
+        g_ws_arena.release(); g_dev_arena.release(); g_pin_arena.release(); g_tend_arena.release(); g_ct_arena.release();
     }
     g_init = false;
     return COLPHYS_OK;
@@ -367,6 +368,18 @@ int colphys_momtran_dev(int ncol, int pver, int pcols, double dt, const colphys_
     return rc ? fail(rc, "momtran launch failed") : COLPHYS_OK;
 }
 
+static std::mutex g_ct_mu;       // own lock: colphys_convtran_chunks calls colphys_convtran_dev with g_mu held
+static int convtran_ws(int ncol, int pcols, int **rows, int **count, int **il2g)
+{
+    std::lock_guard<std::mutex> lk(g_ct_mu);
+    const size_t nchunks = ((size_t)ncol + pcols - 1) / pcols;
+    if (g_ct_arena.reserve(sizeof(int) * ((size_t)ncol + nchunks + 64))) return fail(COLPHYS_ERR_HIP, "convtran workspace allocation failed");
+    *count = (int *)g_ct_arena.p;
+    *rows = *count + 16;
+    *il2g = *rows + ncol;
+    return COLPHYS_OK;
+}
+
 int colphys_convtran_dev(int ncol, int pver, int pcols, int ncnst, double dt, const colphys_convtran_io *io, void *stream)
 {
     (void)dt;
@@ -378,8 +391,41 @@ int colphys_convtran_dev(int ncol, int pver, int pcols, int ncnst, double dt, co
                           io->lengath, io->doconvtran, io->isdry, io->dqdt};
     for (const void *p : ptrs)
         if (!p) return fail(COLPHYS_ERR_ARG, "null pointer in colphys_convtran_io");
+    int *rows, *count, *il2g;
+    if ((rc = convtran_ws(ncol, pcols, &rows, &count, &il2g))) return rc;
     ProfScope ps(COLPHYS_K_CONVTRAN, (hipStream_t)stream);
-    rc = launch_convtran(ncol, pver, pcols, ncnst, *io, (hipStream_t)stream);
+    rc = launch_convtran(ncol, pver, pcols, ncnst, *io, (hipStream_t)stream, nullptr, rows, count, il2g);
+    return rc ? fail(rc, "convtran launch failed") : COLPHYS_OK;
+}
+
+int colphys_zm_conv_tend_2_dev(int ncol, int pver, int pcols, int ncnst, double ztodt, const colphys_zm_conv_tend_2_io *io,
+                               void *stream)
+{
+    (void)ztodt;                                    // convtran's dt only enters the microphysics branch (zm_conv.F90:2254)
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    if (!io) return fail(COLPHYS_ERR_ARG, "null io");
+    if (pcols < 1 || pcols > 1024 || ncnst < 1) return fail(COLPHYS_ERR_ARG, "bad pcols / ncnst");
+    const void *ptrs[] = {io->q, io->fracis, io->mu, io->md, io->du, io->eu, io->ed, io->dp, io->jt, io->maxg, io->ideep, io->lq,
+                          io->isdry, io->ptend_q};
+    for (const void *p : ptrs)
+        if (!p) return fail(COLPHYS_ERR_ARG, "null pointer in colphys_zm_conv_tend_2_io");
+    bool any = false, anydry = false;
+    for (int m = 1; m < ncnst; ++m) {
+        any |= io->lq[m] != 0;
+        anydry |= io->lq[m] != 0 && io->isdry[m] != 0;
+    }
+    if (!any) return COLPHYS_OK;                                                 // zm_conv_intr.F90:1005
+    if (anydry && !io->pdeldry) return fail(COLPHYS_ERR_ARG, "a 'dry' constituent is transported but pdeldry is null");
+    colphys_convtran_io c{};
+    c.q = io->q; c.fracis = io->fracis; c.mu = io->mu; c.md = io->md; c.du = io->du; c.eu = io->eu; c.ed = io->ed; c.dp = io->dp;
+    c.dpdry = io->dp;                               // placeholder, only read for 'dry' constituents, which use pdeldry
+    c.jt = io->jt; c.mx = io->maxg; c.ideep = io->ideep; c.lengath = nullptr;    // count(ideep > 0), :993
+    c.doconvtran = io->lq; c.isdry = io->isdry; c.dqdt = io->ptend_q;
+    int *rows, *count, *il2g;
+    if ((rc = convtran_ws(ncol, pcols, &rows, &count, &il2g))) return rc;
+    ProfScope ps(COLPHYS_K_CONVTRAN, (hipStream_t)stream);
+    rc = launch_convtran(ncol, pver, pcols, ncnst, c, (hipStream_t)stream, anydry ? io->pdeldry : nullptr, rows, count, il2g);
     return rc ? fail(rc, "convtran launch failed") : COLPHYS_OK;
 }
 

@@ -19,7 +19,6 @@
 
 namespace {
 
-constexpr int TILE = 32;      // columns per block
 #ifndef EVAP_TILE
 #define EVAP_TILE 16     // 34 KB of LDS per block at L32: fits the room ONE retiring optics block leaves (A/B: 32 -> 16 columns, substep 2.66 -> 2.58 ms)
 #endif
@@ -277,107 +276,208 @@ __global__ __launch_bounds__(ENT) void zm_conv_evap_kernel(ZmDev P, const double
 }
 
 // ------------------------------------------------------------------------------------------------------
-// convtran :1976-2311 (non-microphysics path): one lane per (gathered column, tracer)
-//   grid.y = tracer m (1-based m+1 = 2..ncnst in the reference); tracers with doconvtran = 0 are skipped on the host.
+// convtran :1976-2311 (non-microphysics path): two launches for ALL transported tracers.
+//
+// convtran_prep_kernel (one block per host chunk): zero-fills dqdt(:,:,m) of every transported tracer (:2299), coalesced,
+//   and appends the chunk's gathered rows (row = chunk*pcols + slot, slot < il2g) to a device-side list.
+//   il2g is lengath[chunk], or count(ideep > 0) when the caller has none (zm_conv_tend_2, zm_conv_intr.F90:993).
+// convtran_wave_kernel (persistent waves over that list): one wave = one gathered row, lane = one transported tracer
+//   (groups of 64 when there are more).  The row's mass-flux profiles (mu md du eu ed dp dpdry) are the same for every
+//   lane: staged once in LDS, read as broadcasts.  Per lane the reference keeps five work profiles; two sweeps need two:
+//     sweep 1, bottom-up : interface value chat(k) (:2117-2141) and the updraft recurrence conu(k) (:2154-2176)
+//                          -> LDS [level][lane] (conflict-free: lanes are contiguous);
+//     sweep 2, top-down  : the downdraft recurrence cond (:2160-2162, 2179-2187) one level ahead in registers, the
+//                          flux-limited tendency (:2190-2262) from chat / conu of levels k, k+1, stored to dqdt.
+//   The constituent and its insoluble fraction are read straight from the full-layout arrays through ideep (:2110-2113):
+//   each lane walks its own contiguous profile, requested two levels ahead of use so that the (strided, one cache line
+//   per 16 levels) misses complete under the recurrence's divisions and the interface logarithm.
+//   dpdry: the gathered array (convtran's argument), or, for zm_conv_tend_2 on resident data, state%pdeldry through ideep,
+//   /100 (zm_conv_intr.F90:1010-1017).
 // ------------------------------------------------------------------------------------------------------
-template <int ML>
-__global__ __launch_bounds__(NT) void convtran_kernel(int ncol, int pver, int pcols, int m, int isdry, colphys_convtran_io io)
+constexpr int CT_MAX = 120;             // transported tracers per launch (kernel-argument list)
+struct ConvtranList {
+    int n;
+    int code[CT_MAX];                   // tracer index (0-based) | dry flag << 30
+};
+
+__global__ __launch_bounds__(256) void convtran_prep_kernel(int ncol, int pver, int pcols, ConvtranList tl, colphys_convtran_io io,
+                                                            int *__restrict__ rows, int *__restrict__ nrows, int *__restrict__ il2g_out)
 {
-    const int row = blockIdx.x * NT + threadIdx.x;
-    if (row >= ncol) return;
-    const int ic = row / pcols, c0 = ic * pcols, slot = row - c0;
-    const int il2g = io.lengath[ic];
-    if (slot >= il2g) return;
+    const int ic = blockIdx.x, c0 = ic * pcols;
+    const int ncc = min(pcols, ncol - c0);
+    const size_t L = (size_t)pver, F = (size_t)ncol * L;
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    int il2g;
+    if (io.lengath) {
+        il2g = io.lengath[ic];
+    } else {
+        int c = 0;
+        for (int j = threadIdx.x; j < ncc; j += blockDim.x) c += io.ideep[c0 + j] > 0 ? 1 : 0;
+        if (c) atomicAdd(&s_cnt, c);
+        __syncthreads();
+        il2g = s_cnt;
+    }
+    if (threadIdx.x == 0) il2g_out[ic] = il2g;
+    for (int j = threadIdx.x; j < il2g; j += blockDim.x) rows[atomicAdd(nrows, 1)] = c0 + j;
+    const size_t n = (size_t)ncc * L;                            // the chunk's slab of one tracer is contiguous
+    for (int t = 0; t < tl.n; ++t) {
+        double *z = io.dqdt + (size_t)(tl.code[t] & 0xffffff) * F + (size_t)c0 * L;
+        for (size_t i = threadIdx.x; i < n; i += blockDim.x) z[i] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(64) void convtran_wave_kernel(int ncol, int pver, int pcols, int ntp, ConvtranList tl, colphys_convtran_io io,
+                                                          const double *__restrict__ pdeldry, const int *__restrict__ rows,
+                                                          const int *__restrict__ nrows, const int *__restrict__ il2g_chunk)
+{
+    // ntp: lanes per row, a power of two >= the tracer count (64 when there are more than 32 tracers: groups of 64);
+    // R = 64 / ntp rows share a wave, lane = (row-in-wave, tracer)
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    const int R = 64 / ntp, rw = lane / ntp, tw = lane - rw * ntp;
+    double *s_chat = smem + lane - 64;                         // element (k, lane) at s_chat[k * 64], k = 1..pver
+    double *s_conu = s_chat + (size_t)pver * 64;
+    double *s_prof = smem + 2 * (size_t)pver * 64 - 1 + (size_t)rw * 7 * pver;   // this lane's row: 7 profiles [pver], 1-based
+    double *s_mu = s_prof, *s_md = s_mu + pver, *s_du = s_md + pver, *s_eu = s_du + pver, *s_ed = s_eu + pver, *s_dp = s_ed + pver,
+           *s_dpd = s_dp + pver;
     const size_t L = (size_t)pver, F = (size_t)ncol * L;
     const double small = 1.e-36, mbsth = 1.e-15;
+    const int count = *nrows;
 
-    int ktm = pver, kbm = pver;                                                  // :2055-2060 (per chunk)
-    for (int i = 0; i < il2g; ++i) {
-        ktm = min(ktm, io.jt[c0 + i]);
-        kbm = min(kbm, io.mx[c0 + i]);
-    }
-    const size_t ii = (size_t)(c0 + io.ideep[row] - 1);
-    const double *mu = io.mu + row * L - 1, *md = io.md + row * L - 1, *du = io.du + row * L - 1,
-                 *eu = io.eu + row * L - 1, *ed = io.ed + row * L - 1, *dp = io.dp + row * L - 1,
-                 *dpdry = io.dpdry + row * L - 1;
-    const double *qm = io.q + m * F + ii * L - 1, *fr = io.fracis + m * F + ii * L - 1;
-    double *dq = io.dqdt + m * F + ii * L - 1;
-    const int mx = io.mx[row];
+    for (int b = blockIdx.x * R; b < count; b += gridDim.x * R) {
+        const bool rvalid = b + rw < count;
+        const int row = rows[rvalid ? b + rw : b];             // lanes past the list shadow the wave's first row (never stored)
+        const int ic = row / pcols, c0 = ic * pcols;
+        const int il2g = il2g_chunk[ic];
+        int ktm = pver, kbm = pver;                                              // :2055-2060 (per chunk)
+        for (int i = 0; i < il2g; ++i) {
+            ktm = min(ktm, io.jt[c0 + i]);
+            kbm = min(kbm, io.mx[c0 + i]);
+        }
+        const size_t ii = (size_t)(c0 + io.ideep[row] - 1);
+        const int mx = io.mx[row];
+        __syncthreads();                                                         // previous rows' readers are done
+        for (int k = tw + 1; k <= pver; k += ntp) {                              // the ntp lanes of a row stage its profiles
+            const size_t g = (size_t)row * L + k - 1;
+            s_mu[k] = io.mu[g]; s_md[k] = io.md[g]; s_du[k] = io.du[g]; s_eu[k] = io.eu[g]; s_ed[k] = io.ed[g]; s_dp[k] = io.dp[g];
+            s_dpd[k] = pdeldry ? pdeldry[ii * L + k - 1] / 100.0 : io.dpdry[g];   // zm_conv_intr.F90:1015
+        }
+        __syncthreads();
 
-    double cnst[ML], chat[ML], cond[ML], conu[ML], efd[ML], edd[ML], dptmp[ML];   // efd = eutmp*fisg*const*dptmp, edd likewise
-    for (int k = 1; k <= pver; ++k) {                                            // :2065-2094
-        double dutmp, eutmp, edtmp;
-        if (isdry) {
-            dptmp[k] = dpdry[k];
-            dutmp = du[k] * dp[k] / dpdry[k];
-            eutmp = eu[k] * dp[k] / dpdry[k];
-            edtmp = ed[k] * dp[k] / dpdry[k];
-        } else {
-            dptmp[k] = dp[k]; dutmp = du[k]; eutmp = eu[k]; edtmp = ed[k];
-        }
-        cnst[k] = qm[k];
-        const double fisg = fr[k];
-        efd[k] = eutmp * fisg * cnst[k] * dptmp[k];                              // as grouped at :2143, :2157
-        edd[k] = edtmp * fisg * cnst[k] * dptmp[k];                              // :2146, :2168
-        conu[k] = dutmp;                                                         // parked until the updraft sweep
-    }
-    for (int k = 1; k <= pver; ++k) {                                            // :2099-2130
-        const int km1 = max(1, k - 1);
-        const double minc = fmin(cnst[km1], cnst[k]), maxc = fmax(cnst[km1], cnst[k]);
-        double cdifr;
-        if (minc < 0) cdifr = 0.0;
-        else cdifr = fabs(cnst[k] - cnst[km1]) / fmax(maxc, small);
-        if (cdifr > 1.E-6) {
-            const double cabv = fmax(cnst[km1], maxc * 1.e-12), cbel = fmax(cnst[k], maxc * 1.e-12);
-            chat[k] = log(cabv / cbel) / (cabv - cbel) * cabv * cbel;
-        } else {
-            chat[k] = 0.5 * (cnst[k] + cnst[km1]);
-        }
-        cond[k] = chat[k];
-    }
-    {                                                                            // :2133-2161 updraft, bottom to top
-        double conu_kp1 = 0.0;
-        for (int kk = pver; kk >= 1; --kk) {
-            const double dutmp = conu[kk];
-            const double mupdudp = mu[kk] + dutmp * dptmp[kk];
-            double cu = chat[kk];
-            if (mupdudp > mbsth) {
-                if (kk == pver) cu = (+efd[kk]) / mupdudp;
-                else cu = (mu[kk + 1] * conu_kp1 + efd[kk]) / mupdudp;
+        for (int g = 0; g < tl.n; g += ntp) {
+            const int t = g + tw;
+            const bool on = rvalid && t < tl.n;
+            const int code = tl.code[t < tl.n ? t : g];
+            const int m = code & 0xffffff;
+            const bool dry = (code >> 30) & 1;
+            const double *qm = io.q + (size_t)m * F + ii * L - 1, *fr = io.fracis + (size_t)m * F + ii * L - 1;
+            double *dq = io.dqdt + (size_t)m * F + ii * L - 1;
+
+            // the four transport profiles of level k as this lane's tracer sees them (:2065-2094)
+            auto fluxes = [&](int k, double &dptmp, double &dutmp, double &eutmp, double &edtmp) {
+                const double dpk = s_dp[k], duk = s_du[k], euk = s_eu[k], edk = s_ed[k];
+                if (dry) {
+                    const double dd = s_dpd[k];
+                    dptmp = dd;
+                    dutmp = fdiv(duk * dpk, dd);
+                    eutmp = fdiv(euk * dpk, dd);
+                    edtmp = fdiv(edk * dpk, dd);
+                } else {
+                    dptmp = dpk; dutmp = duk; eutmp = euk; edtmp = edk;
+                }
+            };
+
+            // ---- sweep 1, bottom-up: chat(k), conu(k) ----
+            {
+                double c_k = qm[pver], conu_kp1 = 0.0;
+                double f_k = fr[pver];
+                // two levels ahead: q(kk-1), q(kk-2) and fracis(kk-1), fracis(kk-2) are in flight while level kk computes
+                double c_n1 = qm[max(1, pver - 1)], c_n2 = qm[max(1, pver - 2)];
+                double f_n1 = fr[max(1, pver - 1)], f_n2 = fr[max(1, pver - 2)];
+                for (int kk = pver; kk >= 1; --kk) {
+                    const double c_km1 = c_n1;                                   // q(max(1, kk-1))
+                    c_n1 = c_n2;
+                    c_n2 = qm[max(1, kk - 3)];
+                    const double minc = fmin(c_km1, c_k), maxc = fmax(c_km1, c_k);   // :2117-2141
+                    double cdifr;
+                    if (minc < 0) cdifr = 0.0;
+                    else cdifr = fabs(c_k - c_km1) / fmax(maxc, small);
+                    double chat;
+                    if (cdifr > 1.E-6) {
+                        const double cabv = fmax(c_km1, maxc * 1.e-12), cbel = fmax(c_k, maxc * 1.e-12);
+                        chat = log(cabv / cbel) / (cabv - cbel) * cabv * cbel;
+                    } else {
+                        chat = 0.5 * (c_k + c_km1);
+                    }
+                    double dptmp, dutmp, eutmp, edtmp;
+                    fluxes(kk, dptmp, dutmp, eutmp, edtmp);
+                    const double efd = eutmp * f_k * c_k * dptmp;                // as grouped at :2157, :2171
+                    const double mupdudp = s_mu[kk] + dutmp * dptmp;
+                    double cu = chat;
+                    if (mupdudp > mbsth) {                                       // > 1e-15: fdiv's operand range
+                        if (kk == pver) cu = fdiv(+efd, mupdudp);
+                        else cu = fdiv(s_mu[kk + 1] * conu_kp1 + efd, mupdudp);
+                    }
+                    s_chat[kk * 64] = chat;
+                    s_conu[kk * 64] = cu;
+                    conu_kp1 = cu;
+                    c_k = c_km1;
+                    f_k = f_n1; f_n1 = f_n2; f_n2 = fr[max(1, kk - 3)];
+                }
             }
-            conu[kk] = cu;
-            conu_kp1 = cu;
-        }
-    }
-    if (md[2] < -mbsth) cond[2] = (-edd[1]) / md[2];                             // :2145-2147
-    for (int k = 3; k <= pver; ++k)                                              // :2164-2172
-        if (md[k] < -mbsth) cond[k] = (md[k - 1] * cond[k - 1] - edd[k - 1]) / md[k];
-
-    for (int k = 1; k <= pver; ++k) {
-        double dcondt = 0.0;
-        if (k >= ktm) {                                                          // :2175-2205
-            const int km1 = max(1, k - 1), kp1 = min(pver, k + 1);
-            const double fluxin = mu[kp1] * conu[kp1] + mu[k] * fmin(chat[k], cnst[km1])
-                                  - (md[k] * cond[k] + md[kp1] * fmin(chat[kp1], cnst[kp1]));
-            const double fluxout = mu[k] * conu[k] + mu[kp1] * fmin(chat[kp1], cnst[k])
-                                   - (md[kp1] * cond[kp1] + md[k] * fmin(chat[k], cnst[k]));
-            double netflux = fluxin - fluxout;
-            if (fabs(netflux) < fmax(fluxin, fluxout) * 1.e-12) netflux = 0.0;
-            dcondt = netflux / dptmp[k];
-        }
-        if (k >= kbm) {                                                          // :2208-2232
-            const int km1 = max(1, k - 1);
-            if (k == mx) {
-                const double fluxin = mu[k] * fmin(chat[k], cnst[km1]) - md[k] * cond[k];
-                const double fluxout = mu[k] * conu[k] - md[k] * fmin(chat[k], cnst[k]);
-                double netflux = fluxin - fluxout;
-                if (fabs(netflux) < fmax(fluxin, fluxout) * 1.e-12) netflux = 0.0;
-                dcondt = netflux / dptmp[k];
-            } else if (k > mx) {
-                dcondt = 0.0;
+            // ---- sweep 2, top-down: cond one level ahead, tendency ----
+            {
+                double c_km1 = qm[1], c_k = qm[1];
+                double c_n1 = qm[min(pver, 2)], c_n2 = qm[min(pver, 3)];
+                double f_k = fr[1], f_n1 = fr[min(pver, 2)];
+                double cond_k = s_chat[64];                                      // cond(1) = chat(1)
+                for (int k = 1; k <= pver; ++k) {
+                    const int kp1 = min(pver, k + 1);
+                    const double c_kp1 = c_n1;                                   // q(min(pver, k+1))
+                    c_n1 = c_n2;
+                    c_n2 = qm[min(pver, k + 3)];
+                    double dptmp, dutmp, eutmp, edtmp;
+                    fluxes(k, dptmp, dutmp, eutmp, edtmp);
+                    const double chat_k = s_chat[k * 64], chat_kp1 = s_chat[kp1 * 64];
+                    const double conu_k = s_conu[k * 64], conu_kp1 = s_conu[kp1 * 64];
+                    const double md_k = s_md[k], md_kp1 = s_md[kp1], mu_k = s_mu[k], mu_kp1 = s_mu[kp1];
+                    // cond(k+1) (:2160-2162 for k+1 = 2, :2179-2187 beyond): provisional chat(k+1) unless the downdraft is active
+                    double cond_kp1 = chat_kp1;
+                    if (k + 1 <= pver && md_kp1 < -mbsth) {
+                        const double edd = edtmp * f_k * c_k * dptmp;
+                        if (k + 1 == 2) cond_kp1 = fdiv(-edd, md_kp1);
+                        else cond_kp1 = fdiv(md_k * cond_k - edd, md_kp1);
+                    }
+                    if (k + 1 > pver) cond_kp1 = cond_k;                         // kp1 == k at the bottom
+                    double dcondt = 0.0;
+                    if (k >= ktm) {                                              // :2190-2220
+                        const double fluxin = mu_kp1 * conu_kp1 + mu_k * fmin(chat_k, c_km1)
+                                              - (md_k * cond_k + md_kp1 * fmin(chat_kp1, c_kp1));
+                        const double fluxout = mu_k * conu_k + mu_kp1 * fmin(chat_kp1, c_k)
+                                               - (md_kp1 * cond_kp1 + md_k * fmin(chat_k, c_k));
+                        double netflux = fluxin - fluxout;
+                        if (fabs(netflux) < fmax(fluxin, fluxout) * 1.e-12) netflux = 0.0;
+                        dcondt = netflux / dptmp;
+                    }
+                    if (k >= kbm) {                                              // :2223-2250
+                        if (k == mx) {
+                            const double fluxin = mu_k * fmin(chat_k, c_km1) - md_k * cond_k;
+                            const double fluxout = mu_k * conu_k - md_k * fmin(chat_k, c_k);
+                            double netflux = fluxin - fluxout;
+                            if (fabs(netflux) < fmax(fluxin, fluxout) * 1.e-12) netflux = 0.0;
+                            dcondt = netflux / dptmp;
+                        } else if (k > mx) {
+                            dcondt = 0.0;
+                        }
+                    }
+                    if (on) dq[k] = dcondt;                                      // :2301-2306
+                    c_km1 = c_k; c_k = c_kp1; cond_k = cond_kp1;
+                    f_k = f_n1; f_n1 = fr[min(pver, k + 2)];
+                }
             }
         }
-        dq[k] = dcondt;                                                          // :2301-2306
     }
 }
 
@@ -456,20 +556,37 @@ int launch_physics_update(int ncol, int pver, double dt, double cpair, double qm
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
 
-int launch_convtran(int ncol, int pver, int pcols, int ncnst, const colphys_convtran_io &io, hipStream_t st)
+int launch_convtran(int ncol, int pver, int pcols, int ncnst, const colphys_convtran_io &io, hipStream_t st, const double *pdeldry,
+                    int *ws_rows, int *ws_count, int *ws_il2g)
 {
-    const size_t n1 = (size_t)ncol * pver;
-    const int nblk = (ncol + NT - 1) / NT;
-    for (int m = 1; m < ncnst; ++m) {                       // do m = 2, ncnst (:2062)
-        if (!io.doconvtran[m]) continue;
-        if (hipMemsetAsync(io.dqdt + (size_t)m * n1, 0, n1 * sizeof(double), st) != hipSuccess) return COLPHYS_ERR_HIP;   // :2299
-        const int dry = io.isdry[m] ? 1 : 0;
-        if (pver <= 32)
-            hipLaunchKernelGGL(convtran_kernel<36>, dim3(nblk), dim3(NT), 0, st, ncol, pver, pcols, m, dry, io);
-        else if (pver <= 72)
-            hipLaunchKernelGGL(convtran_kernel<76>, dim3(nblk), dim3(NT), 0, st, ncol, pver, pcols, m, dry, io);
-        else
-            hipLaunchKernelGGL(convtran_kernel<COLPHYS_MAX_PVER + 4>, dim3(nblk), dim3(NT), 0, st, ncol, pver, pcols, m, dry, io);
+    // lanes per row: the tracer count rounded up to a power of two, at least 8 (several rows share a wave when few
+    // tracers are transported: cloud liquid + ice alone would leave 62 lanes idle), 64 beyond 32 tracers
+    auto lanes_per_row = [](int n) { int p = 8; while (p < n) p <<= 1; return p > 64 ? 64 : p; };
+    auto lds_bytes = [&](int ntp) { return (2 * (size_t)pver * 64 + (size_t)(64 / ntp) * 7 * pver) * sizeof(double); };
+    if (lds_bytes(64) > 160 * 1024) return COLPHYS_ERR_UNSUPPORTED;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void *)convtran_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const int nchunks = (ncol + pcols - 1) / pcols;
+    ConvtranList tl;
+    tl.n = 0;
+    for (int m = 1; m <= ncnst; ++m) {                      // do m = 2, ncnst (:2062); m == ncnst flushes the last group
+        if (m < ncnst && io.doconvtran[m]) tl.code[tl.n++] = m | (io.isdry[m] ? (1 << 30) : 0);
+        if (tl.n == CT_MAX || (m == ncnst && tl.n > 0)) {
+            if (hipMemsetAsync(ws_count, 0, sizeof(int), st) != hipSuccess) return COLPHYS_ERR_HIP;
+            hipLaunchKernelGGL(convtran_prep_kernel, dim3(nchunks), dim3(256), 0, st, ncol, pver, pcols, tl, io, ws_rows, ws_count, ws_il2g);
+            int ntp = lanes_per_row(tl.n);
+            while (ntp < 64 && lds_bytes(ntp) > 160 * 1024) ntp <<= 1;          // long profiles: fewer rows per wave
+            const size_t lds = lds_bytes(ntp);
+            int per_cu = (int)((160 * 1024) / (lds + 256));
+            per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+            const int nper = ncol < 256 * per_cu ? ncol : 256 * per_cu;         // persistent waves over the gathered rows
+            hipLaunchKernelGGL(convtran_wave_kernel, dim3(nper), dim3(64), lds, st, ncol, pver, pcols, ntp, tl, io, pdeldry, ws_rows,
+                               ws_count, ws_il2g);
+            tl.n = 0;
+        }
     }
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }

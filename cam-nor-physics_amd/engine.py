@@ -58,6 +58,7 @@ EXPORTED_SYMBOLS = [
     "colphys_zm_conv_evap_dev", "colphys_zm_conv_evap_chunks",
     "colphys_momtran_dev", "colphys_momtran_chunks",
     "colphys_convtran_dev", "colphys_convtran_chunks", "colphys_physics_update_dev", "colphys_zm_conv_tend_dev",
+    "colphys_zm_conv_tend_2_dev",
     "colphys_aero_tables_set",
     "colphys_modal_aero_sw_dev", "colphys_modal_aero_lw_dev",
     "colphys_modal_aero_sw_chunks", "colphys_modal_aero_lw_chunks",
@@ -230,6 +231,26 @@ class ColumnPhysics:
         self._check(self.lib.colphys_convtran_dev(C.c_int(n), C.c_int(pver), C.c_int(pcols), C.c_int(ncnst), C.c_double(dt),
                                                   C.byref(io), self._stream()))
         return dqdt
+
+    # ---- zm_conv_tend_2 / convtran1 on resident data (zm_conv_intr.F90:955-1028, 860-884) ---------------
+    def zm_conv_tend_2(self, q, fracis, pdeldry, mu, md, du, eu, ed, dp, jt, maxg, ideep, lq, isdry, ztodt, pcols=16, ptend_q=None):
+        """q, fracis, ptend_q: [ncnst][ncol][pver]; lq / isdry: host sequences of ncnst flags; pdeldry may be None when no
+        selected constituent is 'dry'."""
+        ncnst, n, pver = q.shape
+        if ptend_q is None:
+            ptend_q = self.torch.zeros_like(q)
+        io = abi.ZmConvTend2IO()
+        for k, v in dict(q=q, fracis=fracis, mu=mu, md=md, du=du, eu=eu, ed=ed, dp=dp, ptend_q=ptend_q).items():
+            setattr(io, k, _p(self._f64(v)))
+        io.pdeldry = _p(self._f64(pdeldry)) if pdeldry is not None else None
+        for k, v in dict(jt=jt, maxg=maxg, ideep=ideep).items():
+            assert v.dtype == self.torch.int32 and v.is_cuda
+            setattr(io, k, _p(v, abi.PI))
+        lqa = np.ascontiguousarray(lq, dtype=np.int32); dry = np.ascontiguousarray(isdry, dtype=np.int32)
+        io.lq = abi.iptr(lqa); io.isdry = abi.iptr(dry)
+        self._check(self.lib.colphys_zm_conv_tend_2_dev(C.c_int(n), C.c_int(pver), C.c_int(pcols), C.c_int(ncnst),
+                                                        C.c_double(ztodt), C.byref(io), self._stream()))
+        return ptend_q
 
     # ---- physics_update, tendency application (physics_types.F90:292-340,425-432) ---------------------
     def physics_update(self, dt, cpair, qmin=1.0e-12, t=None, q=None, u=None, v=None):

@@ -14,6 +14,8 @@
  *   colphys_zm_conv_evap*            zm_conv_evap             physics/zm_conv.F90:1712-1972
  *   colphys_momtran*                 momtran                  physics/zm_conv.F90:2315-2715
  *   colphys_convtran*                convtran                 physics/zm_conv.F90:1976-2311
+ *   colphys_zm_conv_tend_2_dev       zm_conv_tend_2           physics/zm_conv_intr.F90:955-1028 (and the convtran1
+ *                                    step of zm_conv_tend, :860-884) on resident data
  *   colphys_aero_tables_set          rad_cnst_get_mode_props / rad_cnst_get_aer_props data consumed at
  *                                    physics/modal_aer_opt.F90:717-721,759-762,1334-1355 and the water
  *                                    refractive indices crefwsw/crefwlw :59-60,1525-1530
@@ -57,7 +59,7 @@
 extern "C" {
 #endif
 
-#define COLPHYS_ABI_VERSION 1
+#define COLPHYS_ABI_VERSION 2
 
 #define COLPHYS_OK             0
 #define COLPHYS_ERR_ARG      (-1)
@@ -208,6 +210,30 @@ typedef struct colphys_convtran_io {
 int colphys_convtran_dev(int ncol, int pver, int pcols, int ncnst, double dt, const colphys_convtran_io *io, void *stream);
 int colphys_convtran_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, int ncnst, double dt,
                             const colphys_convtran_io *io);
+
+/* ---------------------------------------------------------------------------------------------------
+ * zm_conv_tend_2 on resident data  (zm_conv_intr.F90:955-1028): convective transport of every constituent with
+ * lq[m] != 0 (cnst_is_convtran2) on the mass fluxes zm_conv_tend left in the physics buffer, ONE launch for all of them:
+ *     lengath = count(ideep > 0) per chunk                                        :993
+ *     dpdry(i,:) = state%pdeldry(ideep(i),:)/100 for the gathered columns         :1010-1017 (done on the fly)
+ *     convtran(lq, state%q, ..., fracis, ptend%q, dpdry, ztodt)                   :1020-1024
+ * The same call with lq = cnst_is_convtran1 is the "convtran1" step that closes zm_conv_tend (:860-884: cloud liquid
+ * and ice, moist mixing ratios; the reference passes a zero dpdry there, so pdeldry may be NULL when no selected
+ * constituent is of type 'dry').  q, fracis, ptend_q are [ncnst][ncol][pver] with water vapour at index 0 (never
+ * transported, zm_conv.F90:2062); ptend_q(:,:,m) is defined for every selected m (zero outside the gathered columns) and
+ * left untouched for the others.  lq, isdry are HOST arrays of ncnst flags.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct colphys_zm_conv_tend_2_io {
+    const double *q, *fracis;                        /* [ncnst][ncol][pver] state%q, pbuf FRACIS */
+    const double *pdeldry;                           /* [ncol][pver] state%pdeldry [Pa] */
+    const double *mu, *md, *du, *eu, *ed, *dp;       /* pbuf ZM_MU ... ZM_DP, gathered [ncol][pver] */
+    const int32_t *jt, *maxg, *ideep;                /* pbuf ZM_JT, ZM_MAXG, ZM_IDEEP, gathered [ncol] */
+    const int32_t *lq, *isdry;                       /* HOST [ncnst] */
+    double *ptend_q;                                 /* [ncnst][ncol][pver] */
+} colphys_zm_conv_tend_2_io;
+
+int colphys_zm_conv_tend_2_dev(int ncol, int pver, int pcols, int ncnst, double ztodt, const colphys_zm_conv_tend_2_io *io,
+                               void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * physics_update, the part the path needs between its three kernels (physics_types.F90:292-340, 425-432;

@@ -1,6 +1,5 @@
-# A/B of environment settings on one box: bash scripts/ab_env.sh [bench args --] "VAR=1 VAR2=2" "VAR=2" ...   (interleaved, REPS rounds)
-ARGS=""
-if [[ "$*" == *" -- "* ]]; then ARGS="${*%% -- *}"; shift $(( $(echo "$ARGS" | wc -w) + 1 )); fi
+# A/B of environment settings on one box: [BENCH_ARGS=...] bash scripts/ab_env.sh "VAR=1 VAR2=2" "VAR=2" ...   (interleaved, REPS rounds)
+ARGS="$BENCH_ARGS"
 mkdir -p gpurun_out
 for rep in $(seq 1 ${REPS:-2}); do
   i=0

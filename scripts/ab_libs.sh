@@ -1,7 +1,6 @@
-# A/B of library builds on one box: bash scripts/ab_libs.sh [bench args --] lib1.so lib2.so ...   (interleaved, REPS rounds each)
+# A/B of library builds on one box: [BENCH_ARGS="--serial --no-graph"] bash scripts/ab_libs.sh lib1.so lib2.so ...   (interleaved, REPS rounds each)
 # Build the variants first: python -c "from cam_nor_physics_amd.build import build_hip; build_hip(extra_flags=[...], out='.../lib_x.so')"
-ARGS=""
-if [[ "$*" == *" -- "* ]]; then ARGS="${*%% -- *}"; set -- ${*#* -- }; fi
+ARGS="$BENCH_ARGS"
 mkdir -p gpurun_out
 for rep in $(seq 1 ${REPS:-2}); do
   for lib in "$@"; do

@@ -107,6 +107,57 @@ def test_evap_and_momtran_vs_reference_golden(name):
     ct = eng.convtran(d(cq), d(cf), d(g["zm_mu"]), d(g["zm_md"]), d(g["zm_du"]), d(g["zm_eu"]), d(g["zm_ed"]), d(g["zm_dp"]), d(cdp),
                       d(g["zm_jt"]), d(g["zm_maxg"]), d(g["zm_ideep"]), d(g["zm_lengath"]), cases.DOCONVTRAN, cases.ISDRY, synth.ZTODT)
     assert_close("convtran.dqdt", ct.cpu().numpy(), g["ct_dqdt"])
+    # zm_conv_tend_2 on resident data (zm_conv_intr.F90:955-1028): the same transport with lengath = count(ideep > 0) and
+    # dpdry gathered from state%pdeldry on the fly -- the reference's convtran output for these inputs is the golden
+    pdeldry = g["in_pdel"] * (1.0 - g["in_q"])
+    t2 = eng.zm_conv_tend_2(d(cq), d(cf), d(pdeldry), d(g["zm_mu"]), d(g["zm_md"]), d(g["zm_du"]), d(g["zm_eu"]), d(g["zm_ed"]),
+                            d(g["zm_dp"]), d(g["zm_jt"]), d(g["zm_maxg"]), d(g["zm_ideep"]), cases.DOCONVTRAN, cases.ISDRY, synth.ZTODT)
+    assert_close("zm_conv_tend_2.ptend_q", t2.cpu().numpy(), g["ct_dqdt"])
+
+
+@pytest.mark.parametrize("ncnst,pver,ncol", [(3, 32, 640), (41, 32, 2000), (70, 32, 1003), (131, 26, 400), (9, 70, 333)])
+def test_convtran_many_tracers_vs_c_oracle(ncnst, pver, ncol):
+    """One launch for all transported tracers (lane = tracer, groups of 64, launches of 120): every grouping boundary,
+    dry and moist constituents mixed, ragged last chunk, against the C restatement; untouched tracers stay untouched."""
+    from c_oracle import COracle
+    params = cases.default_params(pver)
+    eng, co = engine(params), COracle(params)
+    d = eng.dev
+    st = synth.make_state(ncol, pver, 4242 + ncnst)
+    zi, zm = co.geopotential_t(*cases.geo_args(st), st["q"], st["rair"], synth.PHYSCONST["gravit"], st["zvir"])
+    z = co.zm_convr(*cases.zm_args_from_state(st, zi, zm))
+    assert int(z["lengath"].sum()) > 0
+    rng = np.random.default_rng(ncnst)
+    lev = np.linspace(0.0, 1.0, pver)[None, None, :]
+    q = rng.uniform(0.2, 1.0, (ncnst, ncol, 1)) * 1.0e-6 * (0.05 + lev ** rng.uniform(0.5, 3.0, (ncnst, ncol, 1)))
+    q *= 1.0 + 0.2 * rng.standard_normal((ncnst, ncol, pver))
+    q[1 % ncnst, :, : pver // 3] = 0.0
+    q[2 % ncnst, ::5, pver // 2] *= -1.0
+    fracis = rng.uniform(0.0, 1.0, (ncnst, ncol, pver))
+    lq = (rng.uniform(size=ncnst) < 0.8).astype(np.int32); lq[0] = 0; lq[-1] = 1
+    isdry = (rng.uniform(size=ncnst) < 0.4).astype(np.int32)
+    pdeldry = st["pdel"] * (1.0 - st["q"])
+    dpdry = np.ones((ncol, pver))
+    for c in range(len(z["lengath"])):
+        for j in range(int(z["lengath"][c])):
+            row = c * cases.PCOLS + j
+            dpdry[row] = pdeldry[c * cases.PCOLS + int(z["ideep"][row]) - 1] / 100.0
+    ref = co.convtran(q, fracis, z["mu"], z["md"], z["du"], z["eu"], z["ed"], z["dp"], dpdry, z["jt"], z["maxg"], z["ideep"],
+                      z["lengath"], lq, isdry, synth.ZTODT)
+    sentinel = 7.0
+    out = eng.torch.full((ncnst, ncol, pver), sentinel, dtype=eng.torch.float64, device=eng.device)
+    got = eng.zm_conv_tend_2(d(q), d(fracis), d(pdeldry), d(z["mu"]), d(z["md"]), d(z["du"]), d(z["eu"]), d(z["ed"]), d(z["dp"]),
+                             d(z["jt"]), d(z["maxg"]), d(z["ideep"]), lq, isdry, synth.ZTODT, ptend_q=out).cpu().numpy()
+    for m in range(ncnst):
+        if lq[m] and m > 0:
+            assert_close(f"ptend_q[{m}]", got[m], ref[m])
+        else:
+            assert np.all(got[m] == sentinel), m                    # not selected: left untouched (zm_conv.F90:2299 is inside the if)
+    got2 = eng.convtran(d(q), d(fracis), d(z["mu"]), d(z["md"]), d(z["du"]), d(z["eu"]), d(z["ed"]), d(z["dp"]), d(dpdry), d(z["jt"]),
+                        d(z["maxg"]), d(z["ideep"]), d(z["lengath"]), lq, isdry, synth.ZTODT).cpu().numpy()
+    for m in range(1, ncnst):
+        if lq[m]:
+            assert np.array_equal(got2[m], got[m]), m               # gathered dpdry argument == pdeldry gathered on the fly
 
 
 @pytest.mark.parametrize("sw_kernel", ["bands-outer", "grouped"])
