@@ -299,6 +299,25 @@ int colphys_geopotential_t_dev(int ncol, int pver, int dycore_kind, int nq, int 
     return rc ? fail(rc, "geopotential_t launch failed") : COLPHYS_OK;
 }
 
+int colphys_geopotential_dse_dev(int ncol, int pver, int dycore_kind, int nq, int nspecies, const double *piln, const double *pmln,
+                                 const double *pint, const double *pmid, const double *pdel, const double *rpdel, const double *dse,
+                                 const double *q, const double *phis, const double *rair, double gravit, const double *cpair,
+                                 const double *zvir, double *t, double *zi, double *zm, void *stream)
+{
+    (void)pmln;
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    if (dycore_kind < 0 || dycore_kind > 2) return fail(COLPHYS_ERR_ARG, "bad dycore_kind");
+    if (nq < 1 || nspecies < 1 || nspecies > nq) return fail(COLPHYS_ERR_ARG, "need 1 <= nspecies <= nq");
+    if (!dse || !q || !phis || !rair || !cpair || !zvir || !t || !zi || !zm) return fail(COLPHYS_ERR_ARG, "null pointer");
+    if (dycore_kind == COLPHYS_DYCORE_FV ? (!piln || !pint || !rpdel) : (!pdel || !pmid))
+        return fail(COLPHYS_ERR_ARG, "null pressure field for this dycore_kind");
+    ProfScope ps(COLPHYS_K_GEOPOTENTIAL, (hipStream_t)stream);
+    rc = launch_geopotential_dse(ncol, pver, dycore_kind, nspecies, piln, pint, pmid, pdel, rpdel, dse, q, phis, rair, gravit, cpair,
+                                 zvir, t, zi, zm, (hipStream_t)stream);
+    return rc ? fail(rc, "geopotential_dse launch failed") : COLPHYS_OK;
+}
+
 static int zm_convr_impl(int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io *io, void *stream,
                          const ZmTendDiag *diag)
 {
@@ -863,6 +882,38 @@ int colphys_geopotential_t_chunks(int nchunks, int pcols, int pver, const int32_
     rc = colphys_geopotential_t_dev((int)ncd, pver, dycore_kind, nq, nspecies, d_piln, nullptr, d_pint, d_pmid, d_pdel,
                                     d_rpdel, d_t, d_q, d_rair, gravit, d_zvir, d_zi, d_zm, nullptr);
     if (rc) return rc;
+    s.back(zi, d_zi, pverp, false, nullptr);
+    s.back(zm, d_zm, pver, false, nullptr);
+    (void)pmln;
+    s.drain();
+    return s.ok ? COLPHYS_OK : fail(COLPHYS_ERR_HIP, "a staging copy failed");
+}
+
+int colphys_geopotential_dse_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, int dycore_kind, int nq, int nspecies,
+                                    const double *piln, const double *pmln, const double *pint, const double *pmid,
+                                    const double *pdel, const double *rpdel, const double *dse, const double *q, const double *phis,
+                                    const double *rair, double gravit, const double *cpair, const double *zvir, double *t, double *zi,
+                                    double *zm)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t ncd = (size_t)nchunks * pcols, pverp = pver + 1;
+    const size_t bytes = 8 * ncd * (4 * pverp + (10 + (size_t)nq) * pver + 2) + 64 * 256;
+    if ((rc = stage_reserve(bytes, bytes))) return rc;
+    Stager s(nchunks, pcols, ncol, g_pin_arena.p, g_dev_arena.p);
+    const bool fv = dycore_kind == COLPHYS_DYCORE_FV;
+    double *d_piln = fv ? s.in(piln, pverp) : nullptr, *d_pint = fv ? s.in(pint, pverp) : nullptr;
+    double *d_rpdel = fv ? s.in(rpdel, pver) : nullptr;
+    double *d_pmid = fv ? nullptr : s.in(pmid, pver), *d_pdel = fv ? nullptr : s.in(pdel, pver);
+    double *d_dse = s.in(dse, pver), *d_rair = s.in(rair, pver), *d_cpair = s.in(cpair, pver), *d_zvir = s.in(zvir, pver);
+    double *d_phis = s.in(phis, 1);
+    double *d_q = s.in_multi(q, pver, nq);
+    double *d_t = s.out<double>(pver), *d_zi = s.out<double>(pverp), *d_zm = s.out<double>(pver);
+    rc = colphys_geopotential_dse_dev((int)ncd, pver, dycore_kind, nq, nspecies, d_piln, nullptr, d_pint, d_pmid, d_pdel, d_rpdel,
+                                      d_dse, d_q, d_phis, d_rair, gravit, d_cpair, d_zvir, d_t, d_zi, d_zm, nullptr);
+    if (rc) return rc;
+    s.back(t, d_t, pver, false, nullptr);
     s.back(zi, d_zi, pverp, false, nullptr);
     s.back(zm, d_zm, pver, false, nullptr);
     (void)pmln;

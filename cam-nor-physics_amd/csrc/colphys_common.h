@@ -234,6 +234,11 @@ int launch_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspec
                           const double *t, const double *q, const double *rair, double gravit, const double *zvir,
                           double *zi, double *zm, hipStream_t st);
 
+int launch_geopotential_dse(int ncol, int pver, int dycore_kind, int nspecies, const double *piln, const double *pint,
+                            const double *pmid, const double *pdel, const double *rpdel, const double *dse, const double *q,
+                            const double *phis, const double *rair, double gravit, const double *cpair, const double *zvir,
+                            double *t, double *zi, double *zm, hipStream_t st);
+
 struct ZmWorkspace {            // device scratch owned by the API layer (grow-only)
     int *count;                 // [1]   number of first-pass triggered columns
     int *list;                  // [ncol] their column indices (order irrelevant)

@@ -1,6 +1,7 @@
 // k_scans.hip -- the three bandwidth-bound vertical scans of the path, for gfx950:
 //
 //   geopotential_t   /root/reference/physics/geopotential.F90:153-310   bottom-up hydrostatic integration
+//   geopotential_dse /root/reference/physics/geopotential.F90:29-150    the same from dry static energy (T is an output)
 //   zm_conv_evap     /root/reference/physics/zm_conv.F90:1712-1972      top-down precipitation flux / evaporation
 //   convtran         /root/reference/physics/zm_conv.F90:1976-2311      tracer transport on the gathered columns
 //   (momtran lives in k_momtran.hip)
@@ -131,6 +132,96 @@ __global__ __launch_bounds__(GNT) void geopotential_kernel(int ncol, int pver, i
     for (int i = threadIdx.x; i < n; i += GNT) {
         const int cc = i / pver, k = i - cc * pver;
         zm[col0 * L + i] = sZM[cc * ldp + k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// geopotential_dse (geopotential.F90:29-150): temperature and geopotential height from dry static energy.
+//   Same tiling as geopotential_t.  The recurrence carries a division here,
+//       tv = (dse - phis - gravit*zi(k+1)) / (cpair/tvfac + rair*hkk),   zi(k) = zi(k+1) + rog*tv*hkl,
+//   so phase 1 puts everything that does not depend on zi(k+1) into LDS tiles (numerator part dse - phis, denominator,
+//   rog, hkk, hkl), phase 2 walks the column, phase 3 turns tv into t = tv/tvfac element-wise (tvfac recomputed from the
+//   same expression) and stores t, zi, zm coalesced.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double geo_tvfac(int dycore_kind, int nspecies, size_t g, size_t F, const double *__restrict__ q,
+                                            const double *__restrict__ zvir)
+{
+    const double q1 = q[g];
+    if (dycore_kind == COLPHYS_DYCORE_SE) {                    // :118-133, 140
+        double qfac = 1.0, sum_dry = 1.0;
+        for (int idx = 0; idx < nspecies; ++idx) qfac = qfac - q[idx * F + g];
+        qfac = 1.0 / qfac;
+        for (int idx = 0; idx < nspecies; ++idx) sum_dry = sum_dry + q[idx * F + g] * qfac;
+        sum_dry = 1.0 / sum_dry;
+        return (1.0 + (zvir[g] + 1.0) * q1 * qfac) * sum_dry;
+    }
+    return 1.0 + zvir[g] * q1;                                 // :107
+}
+
+__global__ __launch_bounds__(GNT) void geopotential_dse_kernel(int ncol, int pver, int dycore_kind, int nspecies,
+                                                             const double *__restrict__ piln, const double *__restrict__ pint,
+                                                             const double *__restrict__ pmid, const double *__restrict__ pdel,
+                                                             const double *__restrict__ rpdel, const double *__restrict__ dse,
+                                                             const double *__restrict__ q, const double *__restrict__ phis,
+                                                             const double *__restrict__ rair, double gravit,
+                                                             const double *__restrict__ cpair, const double *__restrict__ zvir,
+                                                             double *__restrict__ t, double *__restrict__ zi, double *__restrict__ zm)
+{
+    extern __shared__ double smem[];
+    const int col0 = blockIdx.x * GT;
+    const int nc = min(GT, ncol - col0);
+    const int pverp = pver + 1;
+    const int ldp = ldk_of(pverp);
+    const size_t L = (size_t)pver, LP = (size_t)pverp, F = (size_t)ncol * L;
+    double *sZI = smem;                   // [GT][ldp]: hkl(k), then zi(k); zi(pver+1) = 0 at [pver]
+    double *sZM = sZI + GT * ldp;         // hkk(k), then zm(k)
+    double *sA = sZM + GT * ldp;          // dse - phis, then tv
+    double *sD = sA + GT * ldp;           // cpair/tvfac + rair*hkk
+    double *sR = sD + GT * ldp;           // rog
+
+    const int n = nc * pver;
+    for (int i = threadIdx.x; i < n; i += GNT) {
+        const int c = i / pver, k = i - c * pver;              // 0-based level
+        const size_t g = col0 * L + i, gi = (size_t)(col0 + c) * LP + k;
+        double hkl, hkk;
+        if (dycore_kind == COLPHYS_DYCORE_FV) {                // :93-97
+            hkl = piln[gi + 1] - piln[gi];
+            hkk = 1.0 - pint[gi] * hkl * rpdel[g];
+        } else {                                               // :99-102, 135-138
+            hkl = pdel[g] / pmid[g];
+            hkk = 0.5 * hkl;
+        }
+        const double tvfac = geo_tvfac(dycore_kind, nspecies, g, F, q, zvir);
+        sZI[c * ldp + k] = hkl;
+        sZM[c * ldp + k] = hkk;
+        sA[c * ldp + k] = dse[g] - phis[col0 + c];             // (dse - phis) - gravit*zi : left to right, :108
+        sD[c * ldp + k] = (cpair[g] / tvfac) + rair[g] * hkk;
+        sR[c * ldp + k] = rair[g] / gravit;                    // :78
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < nc) {
+        double zi_kp1 = 0.0;                                   // :81-83
+        sZI[c * ldp + pver] = 0.0;
+        for (int k = pver - 1; k >= 0; --k) {
+            const double tv = (sA[c * ldp + k] - gravit * zi_kp1) / sD[c * ldp + k];
+            const double rt = sR[c * ldp + k] * tv;
+            sA[c * ldp + k] = tv;
+            sZM[c * ldp + k] = zi_kp1 + rt * sZM[c * ldp + k];   // :111
+            zi_kp1 = zi_kp1 + rt * sZI[c * ldp + k];             // :112
+            sZI[c * ldp + k] = zi_kp1;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc * pverp; i += GNT) {
+        const int cc = i / pverp, k = i - cc * pverp;
+        zi[col0 * LP + i] = sZI[cc * ldp + k];
+    }
+    for (int i = threadIdx.x; i < n; i += GNT) {
+        const int cc = i / pver, k = i - cc * pver;
+        const size_t g = col0 * L + i;
+        zm[g] = sZM[cc * ldp + k];
+        t[g] = sA[cc * ldp + k] / geo_tvfac(dycore_kind, nspecies, g, F, q, zvir);   // :110
     }
 }
 
@@ -528,6 +619,20 @@ int launch_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspec
     const int nblk = (ncol + GT - 1) / GT;
     hipLaunchKernelGGL(geopotential_kernel, dim3(nblk), dim3(GNT), lds, st, ncol, pver, dycore_kind, nspecies, piln, pint,
                        pmid, pdel, rpdel, t, q, rair, gravit, zvir, zi, zm);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}
+
+int launch_geopotential_dse(int ncol, int pver, int dycore_kind, int nspecies, const double *piln, const double *pint,
+                            const double *pmid, const double *pdel, const double *rpdel, const double *dse, const double *q,
+                            const double *phis, const double *rair, double gravit, const double *cpair, const double *zvir,
+                            double *t, double *zi, double *zm, hipStream_t st)
+{
+    const int ldp = ((pver + 1) & 1) ? pver + 1 : pver + 2;
+    const size_t lds = (size_t)GT * 5 * ldp * sizeof(double);
+    if (set_lds((const void *)geopotential_dse_kernel, lds)) return COLPHYS_ERR_HIP;
+    const int nblk = (ncol + GT - 1) / GT;
+    hipLaunchKernelGGL(geopotential_dse_kernel, dim3(nblk), dim3(GNT), lds, st, ncol, pver, dycore_kind, nspecies, piln, pint, pmid,
+                       pdel, rpdel, dse, q, phis, rair, gravit, cpair, zvir, t, zi, zm);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
 

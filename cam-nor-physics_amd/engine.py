@@ -53,7 +53,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "colphys_abi_version", "colphys_last_error", "colphys_device_count", "colphys_is_initialized", "colphys_zm_params_defaults",
     "colphys_init", "colphys_finalize",
-    "colphys_geopotential_t_dev", "colphys_geopotential_t_chunks",
+    "colphys_geopotential_t_dev", "colphys_geopotential_t_chunks", "colphys_geopotential_dse_dev", "colphys_geopotential_dse_chunks",
     "colphys_zm_convr_dev", "colphys_zm_convr_chunks",
     "colphys_zm_conv_evap_dev", "colphys_zm_conv_evap_chunks",
     "colphys_momtran_dev", "colphys_momtran_chunks",
@@ -127,6 +127,21 @@ class ColumnPhysics:
             opt(pmid), opt(pdel), opt(rpdel), opt(t), opt(q), opt(rair), C.c_double(gravit), opt(zvir), _p(zi), _p(zm),
             self._stream()))
         return zi, zm
+
+    # ---- geopotential_dse (geopotential.F90:29) ------------------------------------------------------
+    def geopotential_dse(self, piln, pmln, pint, pmid, pdel, rpdel, dse, q, phis, rair, gravit, cpair, zvir,
+                         dycore=abi.DYCORE_FV, nspecies=1):
+        n, pver = dse.shape
+        nq = 1 if q.dim() == 2 else q.shape[0]
+        t, zi, zm = self.empty(n, pver), self.empty(n, pver + 1), self.empty(n, pver)
+
+        def opt(x):
+            return _p(self._f64(x)) if x is not None else None
+        self._check(self.lib.colphys_geopotential_dse_dev(
+            C.c_int(n), C.c_int(pver), C.c_int(dycore), C.c_int(nq), C.c_int(nspecies), opt(piln), opt(pmln), opt(pint),
+            opt(pmid), opt(pdel), opt(rpdel), opt(dse), opt(q), opt(phis), opt(rair), C.c_double(gravit), opt(cpair), opt(zvir),
+            _p(t), _p(zi), _p(zm), self._stream()))
+        return t, zi, zm
 
     # ---- zm_convr (zm_conv.F90:231) ----------------------------------------------------------------
     def alloc_zm_convr_out(self, n, pver, pcols):

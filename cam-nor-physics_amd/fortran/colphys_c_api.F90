@@ -112,6 +112,15 @@ module colphys_c_api
       type(c_ptr), value :: piln, pmln, pint, pmid, pdel, rpdel, t, q, rair, zvir, zi, zm
       real(c_double), value :: gravit
     end function
+    integer(c_int) function colphys_geopotential_dse_chunks(nchunks, pcols, pver, ncol, dycore_kind, nq, nspecies, &
+         piln, pmln, pint, pmid, pdel, rpdel, dse, q, phis, rair, gravit, cpair, zvir, t, zi, zm) &
+         bind(C, name='colphys_geopotential_dse_chunks')
+      import
+      integer(c_int), value :: nchunks, pcols, pver, dycore_kind, nq, nspecies
+      integer(c_int32_t), intent(in) :: ncol(*)
+      type(c_ptr), value :: piln, pmln, pint, pmid, pdel, rpdel, dse, q, phis, rair, cpair, zvir, t, zi, zm
+      real(c_double), value :: gravit
+    end function
     integer(c_int) function colphys_zm_convr_chunks(nchunks, pcols, pver, ncol, delt, io) bind(C, name='colphys_zm_convr_chunks')
       import
       integer(c_int), value :: nchunks, pcols, pver

@@ -8,6 +8,7 @@
  *                                    (+ the physconst values zm_conv.F90:19-20 `use`s, + xrmin/xrmax
  *                                     of modal_aer_opt_init   physics/modal_aer_opt.F90:140-143)
  *   colphys_geopotential_t*          geopotential_t           physics/geopotential.F90:153-310
+ *   colphys_geopotential_dse*        geopotential_dse         physics/geopotential.F90:29-150
  *   colphys_zm_convr*                zm_convr                 physics/zm_conv.F90:231-1709
  *                                    (buoyan_dilute :4425, parcel_dilute :4824, cldprp :3024,
  *                                     closure :4028, q1q2_pjr :4262, entropy/enthalpy/Brent :5280-5570)
@@ -123,6 +124,22 @@ int colphys_geopotential_t_chunks(int nchunks, int pcols, int pver, const int32_
                                   const double *pmid, const double *pdel, const double *rpdel,
                                   const double *t, const double *q, const double *rair, double gravit,
                                   const double *zvir, double *zi, double *zm);
+
+/* ---------------------------------------------------------------------------------------------------
+ * geopotential_dse  (geopotential.F90:29-32): temperature and heights from dry static energy.
+ *   Same conventions as geopotential_t; dse, cpair [ncol][pver], phis [ncol]; outputs t [ncol][pver], zi, zm.
+ * ------------------------------------------------------------------------------------------------- */
+int colphys_geopotential_dse_dev(int ncol, int pver, int dycore_kind, int nq, int nspecies,
+                                 const double *piln, const double *pmln, const double *pint,
+                                 const double *pmid, const double *pdel, const double *rpdel,
+                                 const double *dse, const double *q, const double *phis, const double *rair, double gravit,
+                                 const double *cpair, const double *zvir, double *t, double *zi, double *zm, void *stream);
+
+int colphys_geopotential_dse_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, int dycore_kind, int nq, int nspecies,
+                                    const double *piln, const double *pmln, const double *pint,
+                                    const double *pmid, const double *pdel, const double *rpdel,
+                                    const double *dse, const double *q, const double *phis, const double *rair, double gravit,
+                                    const double *cpair, const double *zvir, double *t, double *zi, double *zm);
 
 /* ---------------------------------------------------------------------------------------------------
  * zm_convr  (zm_conv.F90:231-244; intents :362-423)

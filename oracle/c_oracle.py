@@ -49,6 +49,21 @@ class COracle:
         return zi, zm
 
     # --------------------------------------------------------------------------------------------
+    def geopotential_dse(self, piln, pmln, pint, pmid, pdel, rpdel, dse, q, phis, rair, gravit, cpair, zvir, dycore=1, nspecies=1):
+        n, pver = dse.shape
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        if q.ndim == 2:
+            q = q[None]
+        t = np.zeros((n, pver)); zi = np.zeros((n, pver + 1)); zm = np.zeros((n, pver))
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (piln, pmln, pint, pmid, pdel, rpdel, dse)]
+        f = lambda x: abi.dptr(np.ascontiguousarray(x, dtype=np.float64))
+        keep = [np.ascontiguousarray(x, dtype=np.float64) for x in (phis, rair, cpair, zvir)]
+        self.lib.oracle_geopotential_dse(C.c_int(n), C.c_int(pver), C.c_int(dycore), C.c_int(q.shape[0]), C.c_int(nspecies),
+                                         *[abi.dptr(x) for x in a], abi.dptr(q), abi.dptr(keep[0]), abi.dptr(keep[1]),
+                                         C.c_double(gravit), abi.dptr(keep[2]), abi.dptr(keep[3]), abi.dptr(t), abi.dptr(zi), abi.dptr(zm))
+        return t, zi, zm
+
+    # --------------------------------------------------------------------------------------------
     def zm_convr(self, t, qh, pblh, zm, geos, zi, pap, paph, dpp, delt, tpert, landfrac, pcols=16):
         n, pver = t.shape
         ins = dict(t=t, qh=qh, pap=pap, dpp=dpp, zm=zm, paph=paph, zi=zi, geos=geos, pblh=pblh, tpert=tpert, landfrac=landfrac)

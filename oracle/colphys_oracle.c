@@ -1438,3 +1438,47 @@ void oracle_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspe
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * geopotential_dse  /root/reference/physics/geopotential.F90:29-150
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_geopotential_dse(int ncol, int pver, int dycore_kind, int nq, int nspecies, const double *piln,
+                             const double *pmln, const double *pint, const double *pmid, const double *pdel,
+                             const double *rpdel, const double *dse, const double *q, const double *phis, const double *rair,
+                             double gravit, const double *cpair, const double *zvir, double *t, double *zi, double *zm)
+{
+    const size_t L = (size_t)pver, LP = (size_t)pver + 1, F = (size_t)ncol * L;
+    (void)pmln; (void)nq;
+    for (int ic = 0; ic < ncol; ++ic) {
+        const double *piln_c = piln + ic * LP - 1, *pint_c = pint + ic * LP - 1, *pmid_c = pmid + ic * L - 1,
+                     *pdel_c = pdel + ic * L - 1, *rpdel_c = rpdel + ic * L - 1, *dse_c = dse + ic * L - 1,
+                     *rair_c = rair + ic * L - 1, *cpair_c = cpair + ic * L - 1, *zvir_c = zvir + ic * L - 1;
+        double *zi_c = zi + ic * LP - 1, *zm_c = zm + ic * L - 1, *t_c = t + ic * L - 1;
+        zi_c[pver + 1] = 0.0;                                                    /* :81-83 */
+        for (int k = pver; k >= 1; --k) {
+            double hkl, hkk, tvfac, tv, rog = rair_c[k] / gravit;                /* :78 */
+            const double q1 = q[ic * L + k - 1];
+            if (dycore_kind == COLPHYS_DYCORE_FV) {                              /* :93-97 */
+                hkl = piln_c[k + 1] - piln_c[k];
+                hkk = 1.0 - pint_c[k] * hkl * rpdel_c[k];
+            } else {                                                             /* :99-102 / :135-138 */
+                hkl = pdel_c[k] / pmid_c[k];
+                hkk = 0.5 * hkl;
+            }
+            if (dycore_kind != COLPHYS_DYCORE_SE) {
+                tvfac = 1.0 + zvir_c[k] * q1;                                    /* :107 */
+            } else {                                                             /* :118-133, 140 */
+                double qfac = 1.0, sum_dry = 1.0;
+                for (int idx = 0; idx < nspecies; ++idx) qfac = qfac - q[idx * F + ic * L + k - 1];
+                qfac = 1.0 / qfac;
+                for (int idx = 0; idx < nspecies; ++idx) sum_dry = sum_dry + q[idx * F + ic * L + k - 1] * qfac;
+                sum_dry = 1.0 / sum_dry;
+                tvfac = (1.0 + (zvir_c[k] + 1.0) * q1 * qfac) * sum_dry;
+            }
+            tv = (dse_c[k] - phis[ic] - gravit * zi_c[k + 1]) / ((cpair_c[k] / tvfac) + rair_c[k] * hkk);   /* :108-109 */
+            t_c[k] = tv / tvfac;
+            zm_c[k] = zi_c[k + 1] + rog * tv * hkk;
+            zi_c[k] = zi_c[k + 1] + rog * tv * hkl;
+        }
+    }
+}

@@ -19,6 +19,10 @@ extern "C" {
 
 void oracle_init(const colphys_zm_params *p);
 
+void oracle_geopotential_dse(int ncol, int pver, int dycore_kind, int nq, int nspecies, const double *piln,
+                             const double *pmln, const double *pint, const double *pmid, const double *pdel,
+                             const double *rpdel, const double *dse, const double *q, const double *phis, const double *rair,
+                             double gravit, const double *cpair, const double *zvir, double *t, double *zi, double *zm);
 void oracle_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspecies,
                            const double *piln, const double *pmln, const double *pint, const double *pmid,
                            const double *pdel, const double *rpdel, const double *t, const double *q,

@@ -78,6 +78,20 @@ class RefOracle:
                                     C.c_double(gravit), _d(_c(zvir)), _d(zi), _d(zm))
         return zi, zm
 
+    # -- geopotential_dse --------------------------------------------------------------------------
+    def geopotential_dse(self, piln, pmln, pint, pmid, pdel, rpdel, dse, q, phis, rair, gravit, cpair, zvir, dycore=1, nspecies=1):
+        n, pver = dse.shape
+        q = _c(q)
+        if q.ndim == 2:
+            q = q[None]
+        self.lib.ref_set_dycore(dycore)
+        self.lib.ref_set_thermo_species(nspecies)
+        t = np.zeros((n, pver)); zi = np.zeros((n, pver + 1)); zm = np.zeros((n, pver))
+        args = [_c(a) for a in (piln, pmln, pint, pmid, pdel, rpdel, dse)]
+        self.lib.ref_geopotential_dse(C.c_int(n), C.c_int(q.shape[0]), *[_d(a) for a in args], _d(q), _d(_c(phis)), _d(_c(rair)),
+                                      C.c_double(gravit), _d(_c(cpair)), _d(_c(zvir)), _d(t), _d(zi), _d(zm))
+        return t, zi, zm
+
     # -- zm_convr ----------------------------------------------------------------------------------
     def zm_convr(self, t, qh, pblh, zm, geos, zi, pap, paph, dpp, delt, tpert, landfrac):
         n, pver = t.shape

@@ -17,7 +17,7 @@ module ref_wrap_zm
   use shr_kind_mod,    only: r8 => shr_kind_r8
   use ppgrid,          only: pcols, pver, pverp
   use zm_conv,         only: zm_convi, zm_convr, zm_conv_evap, momtran, convtran
-  use geopotential,    only: geopotential_t
+  use geopotential,    only: geopotential_t, geopotential_dse
   use zm_microphysics, only: zm_conv_t, zm_aero_t
   implicit none
   real(r8), parameter :: pad = huge(1._r8)
@@ -113,6 +113,37 @@ contains
       c0 = c0 + nc
     end do
   end subroutine ref_geopotential_t
+
+  ! ---- geopotential_dse (geopotential.F90:29) ----------------------------------------------------
+  subroutine ref_geopotential_dse(n, nq, piln, pmln, pint, pmid, pdel, rpdel, dse, q, phis, rair, gravit, cpair, zvir, &
+       t, zi, zm) bind(C, name='ref_geopotential_dse')
+    integer(c_int), value :: n, nq
+    real(c_double), intent(in)  :: piln(pverp,n), pmln(pver,n), pint(pverp,n), pmid(pver,n), pdel(pver,n), rpdel(pver,n)
+    real(c_double), intent(in)  :: dse(pver,n), q(pver,n,nq), phis(n), rair(pver,n), cpair(pver,n), zvir(pver,n)
+    real(c_double), value       :: gravit
+    real(c_double), intent(out) :: t(pver,n), zi(pverp,n), zm(pver,n)
+    real(r8) :: piln_c(pcols,pverp), pmln_c(pcols,pver), pint_c(pcols,pverp), pmid_c(pcols,pver), pdel_c(pcols,pver), &
+                rpdel_c(pcols,pver), dse_c(pcols,pver), q_c(pcols,pver,nq), phis_c(pcols), rair_c(pcols,pver), &
+                cpair_c(pcols,pver), zvir_c(pcols,pver), t_c(pcols,pver), zi_c(pcols,pverp), zm_c(pcols,pver)
+    integer :: c0, nc, m
+    c0 = 0
+    do while (c0 < n)
+      nc = min(pcols, n - c0)
+      call pack2(piln, c0, nc, pverp, piln_c); call pack2(pmln, c0, nc, pver, pmln_c)
+      call pack2(pint, c0, nc, pverp, pint_c); call pack2(pmid, c0, nc, pver, pmid_c)
+      call pack2(pdel, c0, nc, pver, pdel_c);  call pack2(rpdel, c0, nc, pver, rpdel_c)
+      call pack2(dse, c0, nc, pver, dse_c)
+      do m = 1, nq
+        call pack2(q(:,:,m), c0, nc, pver, q_c(:,:,m))
+      end do
+      call pack1(phis, c0, nc, phis_c)
+      call pack2(rair, c0, nc, pver, rair_c);  call pack2(cpair, c0, nc, pver, cpair_c); call pack2(zvir, c0, nc, pver, zvir_c)
+      call geopotential_dse(piln_c, pmln_c, pint_c, pmid_c, pdel_c, rpdel_c, dse_c, q_c, phis_c, rair_c, gravit, cpair_c, &
+                            zvir_c, t_c, zi_c, zm_c, nc)
+      call unpack2(t_c, c0, nc, pver, t); call unpack2(zi_c, c0, nc, pverp, zi); call unpack2(zm_c, c0, nc, pver, zm)
+      c0 = c0 + nc
+    end do
+  end subroutine ref_geopotential_dse
 
   ! ---- zm_convr (zm_conv.F90:231) ----------------------------------------------------------------
   subroutine ref_zm_convr(n, t, qh, pblh, zm, geos, zi, pap, paph, dpp, delt, tpert, landfrac, &

@@ -86,3 +86,32 @@ def convtran_inputs(pdel, qv, ideep, lengath, seed, pcols=PCOLS):
             dpdry[row] = pdeldry[c * pcols + int(ideep[row]) - 1] / 100.0
     dpdry[dpdry == 0.0] = 1.0                                   # slots beyond lengath are never read; keep them finite
     return np.ascontiguousarray(q), np.ascontiguousarray(fracis), dpdry
+
+
+def geo_dse_case(ncol, pver, seed, dycore, geo_oracle):
+    """Arguments of geopotential_dse for one dycore branch: dse = cpair*T + gravit*zm + phis with zm from `geo_oracle`'s
+    geopotential_t (any of the oracles: the dse array it yields is stored with the golden, so every implementation is
+    tested on the same bits), cpair varying by 2 % across columns and levels."""
+    st = synth.make_state(ncol, pver, seed)
+    c = synth.PHYSCONST
+    rng = np.random.default_rng(seed + 5)
+    cpair = c["cpair"] * (1.0 + 0.02 * rng.uniform(-1.0, 1.0, (ncol, pver)))
+    nsp = 2 if dycore == 2 else 1
+    q = np.stack([st["q"], 0.1 * st["q"]])
+    _, zm = geo_oracle.geopotential_t(st["lnpint"], st["lnpmid"], st["pint"], st["pmid"], st["pdel"], st["rpdel"], st["t"], q,
+                                      st["rair"], c["gravit"], st["zvir"], dycore=dycore, nspecies=nsp)
+    dse = cpair * st["t"] + c["gravit"] * zm + st["phis"][:, None]
+    args = (st["lnpint"], st["lnpmid"], st["pint"], st["pmid"], st["pdel"], st["rpdel"], dse, q, st["phis"], st["rair"],
+            c["gravit"], cpair, st["zvir"])
+    return dict(args=args, nspecies=nsp, dse=dse, t=st["t"])
+
+
+def geo_dse_args_from_golden(g, tag, ncol, pver, seed, dycore):
+    """The same arguments with the golden's stored dse (bit-identical inputs for every implementation)."""
+    st = synth.make_state(ncol, pver, seed)
+    c = synth.PHYSCONST
+    rng = np.random.default_rng(seed + 5)
+    cpair = c["cpair"] * (1.0 + 0.02 * rng.uniform(-1.0, 1.0, (ncol, pver)))
+    q = np.stack([st["q"], 0.1 * st["q"]])
+    return (st["lnpint"], st["lnpmid"], st["pint"], st["pmid"], st["pdel"], st["rpdel"], g[f"{tag}_dse"], q, st["phis"], st["rair"],
+            c["gravit"], cpair, st["zvir"]), (2 if dycore == 2 else 1), st["t"]

@@ -133,6 +133,21 @@ def evap_cold_golden(ncol, pver, seed):
     return g
 
 
+def geo_dse_golden(ncol, pver, seed):
+    """geopotential_dse (geopotential.F90:29-150) on the synthetic soundings: dry static energy built from T and the
+    reference's own geopotential_t heights, a column-varying cpair, the three dycore branches (SE with two
+    thermodynamically active species)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    ref = RefOracle(PCOLS, pver)
+    g = {"seed": np.int64(seed), "ncol": np.int64(ncol), "pver": np.int64(pver)}
+    for dy, name in ((0, "eul"), (1, "fv"), (2, "se")):
+        a = cases.geo_dse_case(ncol, pver, seed, dy, ref)
+        t, zi, zm = ref.geopotential_dse(*a["args"], dycore=dy, nspecies=a["nspecies"])
+        g[f"{name}_t"] = t; g[f"{name}_zi"] = zi; g[f"{name}_zm"] = zm; g[f"{name}_dse"] = a["dse"]
+    return g
+
+
 AERO_CASES = {"aero_l32": (32, 24, 20261004), "aero_l70": (70, 8, 20261005)}
 
 if __name__ == "__main__":
@@ -146,6 +161,11 @@ if __name__ == "__main__":
         g = evap_cold_golden(48, 32, 21)
         np.savez_compressed(os.path.join(HERE, "evap_cold.npz"), **g)
         print(f"evap_cold: snow max {g['evap_snow'].max():.3e}, melting levels {(g['evap_tend_s_snwevmlt'] != 0).sum()}")
+    if not sys.argv[1:] or "geo_dse" in which:
+        for pver in (32, 70):
+            g = geo_dse_golden(40, pver, 33)
+            np.savez_compressed(os.path.join(HERE, f"geo_dse_l{pver}.npz"), **g)
+            print(f"geo_dse_l{pver}: T range {g['fv_t'].min():.1f} .. {g['fv_t'].max():.1f} K")
     for name in [w for w in which if w in CASES]:
         g = zm_golden(*CASES[name])
         path = os.path.join(HERE, name + ".npz")

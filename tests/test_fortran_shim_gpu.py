@@ -60,6 +60,18 @@ def test_fortran_caller_on_hip_engine_matches_reference_golden(name):
     assert_close("convtran.dqdt", ct, g["ct_dqdt"])
 
 
+@pytest.mark.parametrize("pver", [32, 70])
+def test_fortran_geopotential_dse_on_hip_engine_matches_reference_golden(pver):
+    """module geopotential is replaced whole: geopotential_dse (geopotential.F90:29) through the shim, bit for bit"""
+    g = cases.load_golden(f"geo_dse_l{pver}")
+    f = shim(pver)
+    f.zm_convi(synth.limcnv_from_pref(pver), synth.ZM_NAMELIST)     # colphys_init
+    for dy, tag in ((0, "eul"), (1, "fv"), (2, "se")):
+        args, nsp, _ = cases.geo_dse_args_from_golden(g, tag, int(g["ncol"]), pver, int(g["seed"]), dy)
+        t, zi, zm = f.geopotential_dse(*args, dycore=dy, nspecies=nsp)
+        assert np.array_equal(t, g[f"{tag}_t"]) and np.array_equal(zi, g[f"{tag}_zi"]) and np.array_equal(zm, g[f"{tag}_zm"]), tag
+
+
 @pytest.mark.parametrize("name", cases.AERO_GOLDEN)
 def test_fortran_optics_caller_on_hip_engine_matches_reference_golden(name):
     """`module modal_aer_opt` built from the shim, driven by the caller source that drives the reference's module

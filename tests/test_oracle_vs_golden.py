@@ -50,6 +50,19 @@ def test_geopotential_vs_reference_golden(name):
         assert np.array_equal(zi, g[f"geo_{tag}_zi"]) and np.array_equal(zm, g[f"geo_{tag}_zm"]), tag   # bit-exact
 
 
+@pytest.mark.parametrize("pver", [32, 70])
+def test_geopotential_dse_vs_reference_golden(pver):
+    """geopotential_dse (geopotential.F90:29-150), three dycore branches, bit-exact against the reference build; and the
+    round trip dse(T) -> T recovers the temperature the dry static energy was built from."""
+    g = cases.load_golden(f"geo_dse_l{pver}")
+    co = COracle(cases.default_params(pver))
+    for dy, tag in ((abi.DYCORE_EUL, "eul"), (abi.DYCORE_FV, "fv"), (abi.DYCORE_SE, "se")):
+        args, nsp, t_true = cases.geo_dse_args_from_golden(g, tag, int(g["ncol"]), pver, int(g["seed"]), dy)
+        t, zi, zm = co.geopotential_dse(*args, dycore=dy, nspecies=nsp)
+        assert np.array_equal(t, g[f"{tag}_t"]) and np.array_equal(zi, g[f"{tag}_zi"]) and np.array_equal(zm, g[f"{tag}_zm"]), tag
+        assert np.max(np.abs(t - t_true) / t_true) < 1e-12, tag
+
+
 @pytest.mark.parametrize("name", cases.AERO_GOLDEN)
 def test_modal_aero_vs_reference_golden(name):
     g = cases.load_golden(name)

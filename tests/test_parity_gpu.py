@@ -88,6 +88,40 @@ def test_geopotential_vs_reference_golden(name):
         assert_close(f"geopotential_t[{tag}].zm", zm.cpu().numpy(), g[f"geo_{tag}_zm"])
 
 
+@pytest.mark.parametrize("pver", [32, 70])
+def test_geopotential_dse_vs_reference_golden(pver):
+    g = cases.load_golden(f"geo_dse_l{pver}")
+    eng = engine(cases.default_params(pver))
+    d = eng.dev
+    for dy, tag in ((abi.DYCORE_EUL, "eul"), (abi.DYCORE_FV, "fv"), (abi.DYCORE_SE, "se")):
+        args, nsp, t_true = cases.geo_dse_args_from_golden(g, tag, int(g["ncol"]), pver, int(g["seed"]), dy)
+        a = [d(x) if isinstance(x, np.ndarray) else x for x in args]
+        t, zi, zm = eng.geopotential_dse(*a, dycore=dy, nspecies=nsp)
+        # the same IEEE operations in the same order: bit-exact, like geopotential_t
+        assert np.array_equal(t.cpu().numpy(), g[f"{tag}_t"]), tag
+        assert np.array_equal(zi.cpu().numpy(), g[f"{tag}_zi"]) and np.array_equal(zm.cpu().numpy(), g[f"{tag}_zm"]), tag
+
+
+def test_geopotential_dse_full_size_round_trip():
+    """48 602 columns (ragged last tile): T -> dse with the engine's own geopotential_t heights -> geopotential_dse gives the
+    temperature and the heights back (size-independent property)."""
+    pver, ncol = 32, 48602
+    eng = engine(cases.default_params(pver))
+    d = eng.dev
+    st = synth.make_state(ncol, pver, 99)
+    c = synth.PHYSCONST
+    S = {k: d(st[k]) for k in ("lnpint", "lnpmid", "pint", "pmid", "pdel", "rpdel", "t", "q", "rair", "zvir", "phis")}
+    zi, zm = eng.geopotential_t(S["lnpint"], S["lnpmid"], S["pint"], S["pmid"], S["pdel"], S["rpdel"], S["t"], S["q"], S["rair"],
+                                c["gravit"], S["zvir"])
+    cpair = eng.torch.full_like(S["t"], c["cpair"])
+    dse = cpair * S["t"] + c["gravit"] * zm + S["phis"][:, None]
+    t2, zi2, zm2 = eng.geopotential_dse(S["lnpint"], S["lnpmid"], S["pint"], S["pmid"], S["pdel"], S["rpdel"], dse, S["q"], S["phis"],
+                                        S["rair"], c["gravit"], cpair, S["zvir"])
+    assert float(((t2 - S["t"]).abs() / S["t"]).max()) < 1e-12
+    assert float(((zi2 - zi).abs().max(dim=1).values / zi.abs().max(dim=1).values).max()) < 1e-12
+    assert float(((zm2 - zm).abs().max(dim=1).values / zm.abs().max(dim=1).values).max()) < 1e-12
+
+
 @pytest.mark.parametrize("name", cases.ZM_GOLDEN)
 def test_evap_and_momtran_vs_reference_golden(name):
     g = cases.load_golden(name)
