@@ -106,6 +106,14 @@ class ConvtranIO(C.Structure):
     )
 
 
+CONVECT_DIAG_FIELDS = ("cmfmc", "qc", "rliq", "cnt", "cnb", "cmfmc2", "qc2", "rprdsh", "rliq2", "cnt2", "cnb2", "precc", "snow",
+                       "icwmr", "evapcsh", "rprddp", "pmid", "rprdtot", "pcnt", "pcnb")
+
+
+class ConvectDiagIO(C.Structure):
+    _fields_ = [(n, PD) for n in CONVECT_DIAG_FIELDS]
+
+
 class ZmConvTend2IO(C.Structure):
     _fields_ = (
         [(n, PD) for n in ("q", "fracis", "pdeldry", "mu", "md", "du", "eu", "ed", "dp")]

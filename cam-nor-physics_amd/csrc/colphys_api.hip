@@ -448,6 +448,23 @@ int colphys_zm_conv_tend_2_dev(int ncol, int pver, int pcols, int ncnst, double 
     return rc ? fail(rc, "convtran launch failed") : COLPHYS_OK;
 }
 
+int colphys_convect_diagnostics_dev(int ncol, int pver, int shallow_is_clubb, const colphys_convect_diag_io *io, void *stream)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    if (!io) return fail(COLPHYS_ERR_ARG, "null io");
+    const void *need[] = {io->cmfmc, io->qc, io->rliq, io->cnt, io->cnb, io->rprddp, io->pmid, io->rprdtot, io->pcnt, io->pcnb};
+    for (const void *p : need)
+        if (!p) return fail(COLPHYS_ERR_ARG, "null pointer in colphys_convect_diag_io");
+    if (!shallow_is_clubb) {
+        const void *sh[] = {io->cmfmc2, io->qc2, io->rprdsh, io->rliq2, io->cnt2, io->cnb2};
+        for (const void *p : sh)
+            if (!p) return fail(COLPHYS_ERR_ARG, "a shallow-scheme field is null and shallow_is_clubb is 0");
+    }
+    rc = launch_convect_diag(ncol, pver, shallow_is_clubb ? 1 : 0, *io, (hipStream_t)stream);
+    return rc ? fail(rc, "convect_diagnostics launch failed") : COLPHYS_OK;
+}
+
 int colphys_physics_update_dev(int ncol, int pver, double dt, double cpair, double qmin, const double *t_in,
                                const double *s_tend, double *t_out, const double *q_in, const double *q_tend, double *q_out,
                                const double *u_in, const double *u_tend, double *u_out, const double *v_in,

@@ -696,6 +696,60 @@ int launch_convtran(int ncol, int pver, int pcols, int ncnst, const colphys_conv
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
 
+// ---- convect_diagnostics_calc (convect_diagnostics.F90:115-249): element-wise merge, grid-stride ------------------
+namespace {
+__global__ void convect_diag_kernel(int ncol, int pver, int clubb, colphys_convect_diag_io io)
+{
+    const size_t L = (size_t)pver, LP = L + 1, nM = (size_t)ncol * L, nI = (size_t)ncol * LP;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = i0; i < nI; i += stride) {
+        if (clubb) { if (io.cmfmc2) io.cmfmc2[i] = 0.0; }                        // :179
+        else io.cmfmc[i] = io.cmfmc[i] + io.cmfmc2[i];                           // :199 (+0 under CLUBB: unchanged bits)
+    }
+    for (size_t i = i0; i < nM; i += stride) {
+        double rsh, q2;
+        if (clubb) {                                                             // :180-188
+            rsh = 0.0; q2 = 0.0;
+            if (io.rprdsh) io.rprdsh[i] = 0.0;
+            if (io.qc2) io.qc2[i] = 0.0;
+            if (io.icwmr) io.icwmr[i] = 0.0;
+            if (io.evapcsh) io.evapcsh[i] = 0.0;
+        } else {
+            rsh = io.rprdsh[i]; q2 = io.qc2[i];
+        }
+        io.rprdtot[i] = rsh + io.rprddp[i];                                      // :223
+        io.qc[i] = io.qc[i] + q2;                                                // :230
+    }
+    for (size_t c = i0; c < (size_t)ncol; c += stride) {
+        double t2, b2, l2;
+        if (clubb) {
+            t2 = (double)pver; b2 = 1.0; l2 = 0.0;                               // :185-186, 183
+            if (io.rliq2) io.rliq2[c] = 0.0;
+            if (io.precc) io.precc[c] = 0.0;
+            if (io.snow) io.snow[c] = 0.0;
+        } else {
+            t2 = io.cnt2[c]; b2 = io.cnb2[c]; l2 = io.rliq2[c];
+        }
+        double cnt = io.cnt[c], cnb = io.cnb[c];
+        if (t2 < cnt) cnt = t2;                                                  // :210-216
+        if (b2 > cnb) cnb = b2;
+        if (cnb == 1.0) cnb = cnt;
+        io.cnt[c] = cnt; io.cnb[c] = cnb;
+        io.pcnt[c] = io.pmid[c * L + ((int)cnt - 1)];
+        io.pcnb[c] = io.pmid[c * L + ((int)cnb - 1)];
+        io.rliq[c] = io.rliq[c] + l2;                                            // :231
+    }
+}
+}  // namespace
+
+int launch_convect_diag(int ncol, int pver, int clubb, const colphys_convect_diag_io &io, hipStream_t st)
+{
+    const size_t n = (size_t)ncol * (pver + 1);
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(convect_diag_kernel, dim3(blocks), dim3(256), 0, st, ncol, pver, clubb, io);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}
+
 // ---- diagnostic probe of the scalar device functions (colphys_math_probe_dev) ----------------------------
 namespace {
 __global__ void math_probe_kernel(int kind, int64_t n, const double *__restrict__ x, double *__restrict__ y)

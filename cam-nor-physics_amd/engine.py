@@ -58,7 +58,7 @@ EXPORTED_SYMBOLS = [
     "colphys_zm_conv_evap_dev", "colphys_zm_conv_evap_chunks",
     "colphys_momtran_dev", "colphys_momtran_chunks",
     "colphys_convtran_dev", "colphys_convtran_chunks", "colphys_physics_update_dev", "colphys_zm_conv_tend_dev",
-    "colphys_zm_conv_tend_2_dev",
+    "colphys_zm_conv_tend_2_dev", "colphys_convect_diagnostics_dev",
     "colphys_aero_tables_set",
     "colphys_modal_aero_sw_dev", "colphys_modal_aero_lw_dev",
     "colphys_modal_aero_sw_chunks", "colphys_modal_aero_lw_chunks",
@@ -266,6 +266,18 @@ class ColumnPhysics:
         self._check(self.lib.colphys_zm_conv_tend_2_dev(C.c_int(n), C.c_int(pver), C.c_int(pcols), C.c_int(ncnst),
                                                         C.c_double(ztodt), C.byref(io), self._stream()))
         return ptend_q
+
+    # ---- convect_diagnostics_calc (convect_diagnostics.F90:115-249) --------------------------------------
+    def convect_diagnostics(self, fields: dict, shallow_is_clubb: bool):
+        """fields: device tensors named as abi.CONVECT_DIAG_FIELDS (missing / None = NULL); updates in place, fills rprdtot, pcnt, pcnb"""
+        n, pver = fields["qc"].shape
+        io = abi.ConvectDiagIO()
+        for k in abi.CONVECT_DIAG_FIELDS:
+            v = fields.get(k)
+            setattr(io, k, _p(self._f64(v)) if v is not None else None)
+        self._check(self.lib.colphys_convect_diagnostics_dev(C.c_int(n), C.c_int(pver), C.c_int(1 if shallow_is_clubb else 0),
+                                                             C.byref(io), self._stream()))
+        return fields
 
     # ---- physics_update, tendency application (physics_types.F90:292-340,425-432) ---------------------
     def physics_update(self, dt, cpair, qmin=1.0e-12, t=None, q=None, u=None, v=None):

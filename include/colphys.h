@@ -15,6 +15,7 @@
  *   colphys_zm_conv_evap*            zm_conv_evap             physics/zm_conv.F90:1712-1972
  *   colphys_momtran*                 momtran                  physics/zm_conv.F90:2315-2715
  *   colphys_convtran*                convtran                 physics/zm_conv.F90:1976-2311
+ *   colphys_convect_diagnostics_dev  convect_diagnostics_calc physics/convect_diagnostics.F90:115-249
  *   colphys_zm_conv_tend_2_dev       zm_conv_tend_2           physics/zm_conv_intr.F90:955-1028 (and the convtran1
  *                                    step of zm_conv_tend, :860-884) on resident data
  *   colphys_aero_tables_set          rad_cnst_get_mode_props / rad_cnst_get_aer_props data consumed at
@@ -251,6 +252,33 @@ typedef struct colphys_zm_conv_tend_2_io {
 
 int colphys_zm_conv_tend_2_dev(int ncol, int pver, int pcols, int ncnst, double ztodt, const colphys_zm_conv_tend_2_io *io,
                                void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * convect_diagnostics_calc  (convect_diagnostics.F90:115-249): merges the deep scheme's outputs with the shallow scheme's
+ * on resident data, element-wise.
+ *     shallow_is_clubb != 0 ('CLUBB_SGS', :178-189): cmfmc2, rprdsh, precc, icwmr, rliq2, qc2, evapcsh, snow are ZEROED
+ *         first (each may be NULL), cnt2 = pver, cnb2 = 1 (the cnt2 / cnb2 arguments are ignored);
+ *     cmfmc += cmfmc2 (:199); cnt = min(cnt, cnt2), cnb = max(cnb, cnb2), cnb == 1 -> cnb = cnt,
+ *     pcnt = pmid(int(cnt)), pcnb = pmid(int(cnb)) (:210-216); rprdtot = rprdsh + rprddp (:223);
+ *     qc += qc2, rliq += rliq2 (:230-231).
+ * cnt / cnb are the real-valued level indices zm_convr returns as jctop / jcbot (pbuf CLDTOP / CLDBOT).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct colphys_convect_diag_io {
+    double *cmfmc;                                   /* [ncol][pver+1] in/out */
+    double *qc;                                      /* [ncol][pver]   in/out */
+    double *rliq, *cnt, *cnb;                        /* [ncol]         in/out */
+    double *cmfmc2;                                  /* [ncol][pver+1] shallow mass flux (zeroed under CLUBB) */
+    double *qc2, *rprdsh;                            /* [ncol][pver] */
+    double *rliq2;                                   /* [ncol] */
+    const double *cnt2, *cnb2;                       /* [ncol], shallow top / base (ignored under CLUBB) */
+    double *precc, *snow;                            /* [ncol]         zeroed under CLUBB, untouched otherwise; may be NULL */
+    double *icwmr, *evapcsh;                         /* [ncol][pver]   zeroed under CLUBB, untouched otherwise; may be NULL */
+    const double *rprddp, *pmid;                     /* [ncol][pver] */
+    double *rprdtot;                                 /* [ncol][pver] out */
+    double *pcnt, *pcnb;                             /* [ncol] out */
+} colphys_convect_diag_io;
+
+int colphys_convect_diagnostics_dev(int ncol, int pver, int shallow_is_clubb, const colphys_convect_diag_io *io, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * physics_update, the part the path needs between its three kernels (physics_types.F90:292-340, 425-432;

@@ -49,6 +49,19 @@ class COracle:
         return zi, zm
 
     # --------------------------------------------------------------------------------------------
+    def convect_diagnostics(self, fields: dict, shallow_is_clubb: bool):
+        """fields: numpy arrays named as abi.CONVECT_DIAG_FIELDS (missing = NULL); in/out arrays are updated in place"""
+        n, pver = fields["qc"].shape
+        io = abi.ConvectDiagIO()
+        for k in abi.CONVECT_DIAG_FIELDS:
+            v = fields.get(k)
+            if v is not None:
+                assert v.dtype == np.float64 and v.flags["C_CONTIGUOUS"], k
+                setattr(io, k, abi.dptr(v))
+        self.lib.oracle_convect_diagnostics(C.c_int(n), C.c_int(pver), C.c_int(1 if shallow_is_clubb else 0), C.byref(io))
+        return fields
+
+    # --------------------------------------------------------------------------------------------
     def geopotential_dse(self, piln, pmln, pint, pmid, pdel, rpdel, dse, q, phis, rair, gravit, cpair, zvir, dycore=1, nspecies=1):
         n, pver = dse.shape
         q = np.ascontiguousarray(q, dtype=np.float64)

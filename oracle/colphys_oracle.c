@@ -1482,3 +1482,42 @@ void oracle_geopotential_dse(int ncol, int pver, int dycore_kind, int nq, int ns
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * convect_diagnostics_calc  /root/reference/physics/convect_diagnostics.F90:115-249
+ * (parity unpinned against a reference BUILD: the module needs physics_types / physics_buffer of the parent model;
+ *  this is a line-by-line restatement of :178-231, checked in tests/ against an independent numpy restatement)
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_convect_diagnostics(int ncol, int pver, int clubb, const colphys_convect_diag_io *io)
+{
+    const size_t L = (size_t)pver, LP = L + 1;
+    for (int i = 0; i < ncol; ++i) {
+        double cnt2, cnb2;
+        if (clubb) {                                                             /* :178-189 */
+            for (size_t k = 0; k < LP; ++k) if (io->cmfmc2) io->cmfmc2[i * LP + k] = 0.0;
+            for (size_t k = 0; k < L; ++k) {
+                if (io->rprdsh) io->rprdsh[i * L + k] = 0.0;
+                if (io->icwmr) io->icwmr[i * L + k] = 0.0;
+                if (io->qc2) io->qc2[i * L + k] = 0.0;
+                if (io->evapcsh) io->evapcsh[i * L + k] = 0.0;
+            }
+            if (io->precc) io->precc[i] = 0.0;
+            if (io->rliq2) io->rliq2[i] = 0.0;
+            if (io->snow) io->snow[i] = 0.0;
+            cnt2 = (double)pver; cnb2 = 1.0;
+        } else {
+            cnt2 = io->cnt2[i]; cnb2 = io->cnb2[i];
+        }
+        for (size_t k = 0; k < LP; ++k) io->cmfmc[i * LP + k] = io->cmfmc[i * LP + k] + (clubb ? 0.0 : io->cmfmc2[i * LP + k]);   /* :199 */
+        if (cnt2 < io->cnt[i]) io->cnt[i] = cnt2;                                /* :210-216 */
+        if (cnb2 > io->cnb[i]) io->cnb[i] = cnb2;
+        if (io->cnb[i] == 1.0) io->cnb[i] = io->cnt[i];
+        io->pcnt[i] = io->pmid[i * L + ((int)io->cnt[i] - 1)];
+        io->pcnb[i] = io->pmid[i * L + ((int)io->cnb[i] - 1)];
+        for (size_t k = 0; k < L; ++k) {
+            io->rprdtot[i * L + k] = (clubb ? 0.0 : io->rprdsh[i * L + k]) + io->rprddp[i * L + k];   /* :223 */
+            io->qc[i * L + k] = io->qc[i * L + k] + (clubb ? 0.0 : io->qc2[i * L + k]);              /* :230 */
+        }
+        io->rliq[i] = io->rliq[i] + (clubb ? 0.0 : io->rliq2[i]);               /* :231 */
+    }
+}

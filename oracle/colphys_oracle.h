@@ -19,6 +19,7 @@ extern "C" {
 
 void oracle_init(const colphys_zm_params *p);
 
+void oracle_convect_diagnostics(int ncol, int pver, int clubb, const colphys_convect_diag_io *io);
 void oracle_geopotential_dse(int ncol, int pver, int dycore_kind, int nq, int nspecies, const double *piln,
                              const double *pmln, const double *pint, const double *pmid, const double *pdel,
                              const double *rpdel, const double *dse, const double *q, const double *phis, const double *rair,

@@ -115,3 +115,49 @@ def geo_dse_args_from_golden(g, tag, ncol, pver, seed, dycore):
     q = np.stack([st["q"], 0.1 * st["q"]])
     return (st["lnpint"], st["lnpmid"], st["pint"], st["pmid"], st["pdel"], st["rpdel"], g[f"{tag}_dse"], q, st["phis"], st["rair"],
             c["gravit"], cpair, st["zvir"]), (2 if dycore == 2 else 1), st["t"]
+
+
+def convect_diag_case(ncol, pver, seed):
+    """Inputs of convect_diagnostics_calc (convect_diagnostics.F90:115-249): deep outputs shaped like zm_conv_tend's
+    (cloud top / base as real-valued level indices, pver / 1 where nothing convects) and a synthetic shallow scheme."""
+    rng = np.random.default_rng(seed)
+    st = synth.make_state(ncol, pver, seed)
+    deep = rng.uniform(size=ncol) < 0.3
+    cnt = np.where(deep, rng.integers(pver // 3, pver - 3, ncol), pver).astype(np.float64)
+    cnb = np.where(deep, rng.integers(pver - 3, pver + 1, ncol), 1).astype(np.float64)
+    sh = rng.uniform(size=ncol) < 0.5
+    f = dict(
+        cmfmc=rng.uniform(0, 0.05, (ncol, pver + 1)) * deep[:, None], qc=rng.uniform(0, 1e-8, (ncol, pver)) * deep[:, None],
+        rliq=rng.uniform(0, 1e-8, ncol) * deep, cnt=cnt, cnb=cnb,
+        cmfmc2=rng.uniform(0, 0.02, (ncol, pver + 1)) * sh[:, None], qc2=rng.uniform(0, 1e-8, (ncol, pver)) * sh[:, None],
+        rprdsh=rng.uniform(0, 1e-8, (ncol, pver)), rliq2=rng.uniform(0, 1e-8, ncol) * sh,
+        cnt2=np.where(sh, rng.integers(pver // 2, pver - 1, ncol), pver).astype(np.float64),
+        cnb2=np.where(sh, rng.integers(pver - 2, pver + 1, ncol), 1).astype(np.float64),
+        precc=rng.uniform(0, 1e-7, ncol), snow=rng.uniform(0, 1e-8, ncol), icwmr=rng.uniform(0, 1e-4, (ncol, pver)),
+        evapcsh=rng.uniform(0, 1e-8, (ncol, pver)), rprddp=rng.uniform(0, 1e-8, (ncol, pver)) * deep[:, None], pmid=st["pmid"],
+        rprdtot=np.full((ncol, pver), np.nan), pcnt=np.full(ncol, np.nan), pcnb=np.full(ncol, np.nan))
+    return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in f.items()}
+
+
+def convect_diag_numpy(f, clubb):
+    """Independent restatement (array form) of convect_diagnostics.F90:178-231"""
+    o = {k: v.copy() for k, v in f.items()}
+    pver = o["qc"].shape[1]
+    if clubb:
+        for k in ("cmfmc2", "rprdsh", "precc", "icwmr", "rliq2", "qc2", "evapcsh", "snow"):
+            o[k][...] = 0.0
+        cnt2, cnb2 = np.full_like(o["cnt"], pver), np.ones_like(o["cnb"])
+    else:
+        cnt2, cnb2 = o["cnt2"], o["cnb2"]
+    o["cmfmc"] = o["cmfmc"] + o["cmfmc2"]
+    cnt = np.where(cnt2 < o["cnt"], cnt2, o["cnt"])
+    cnb = np.where(cnb2 > o["cnb"], cnb2, o["cnb"])
+    cnb = np.where(cnb == 1.0, cnt, cnb)
+    idx = np.arange(len(cnt))
+    o["cnt"], o["cnb"] = cnt, cnb
+    o["pcnt"] = o["pmid"][idx, cnt.astype(int) - 1]
+    o["pcnb"] = o["pmid"][idx, cnb.astype(int) - 1]
+    o["rprdtot"] = o["rprdsh"] + o["rprddp"]
+    o["qc"] = o["qc"] + o["qc2"]
+    o["rliq"] = o["rliq"] + o["rliq2"]
+    return o

@@ -63,6 +63,17 @@ def test_geopotential_dse_vs_reference_golden(pver):
         assert np.max(np.abs(t - t_true) / t_true) < 1e-12, tag
 
 
+@pytest.mark.parametrize("clubb", [True, False])
+def test_convect_diagnostics_restatement_against_array_form(clubb):
+    """convect_diagnostics_calc cannot be built from the reference alone (it needs the parent model's physics_types /
+    physics_buffer): the C restatement of :178-231 is checked against an independent array-form restatement instead."""
+    f = cases.convect_diag_case(333, 32, 5)
+    want = cases.convect_diag_numpy(f, clubb)
+    got = COracle(cases.default_params(32)).convect_diagnostics({k: v.copy() for k, v in f.items()}, clubb)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+
+
 @pytest.mark.parametrize("name", cases.AERO_GOLDEN)
 def test_modal_aero_vs_reference_golden(name):
     g = cases.load_golden(name)

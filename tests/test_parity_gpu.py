@@ -122,6 +122,24 @@ def test_geopotential_dse_full_size_round_trip():
     assert float(((zm2 - zm).abs().max(dim=1).values / zm.abs().max(dim=1).values).max()) < 1e-12
 
 
+@pytest.mark.parametrize("clubb", [True, False])
+@pytest.mark.parametrize("ncol,pver", [(1003, 32), (48602, 32), (257, 70)])
+def test_convect_diagnostics_vs_c_oracle(ncol, pver, clubb):
+    from c_oracle import COracle
+    f = cases.convect_diag_case(ncol, pver, 8 + ncol)
+    params = cases.default_params(pver)
+    want = COracle(params).convect_diagnostics({k: v.copy() for k, v in f.items()}, clubb)
+    eng = engine(params)
+    got = eng.convect_diagnostics({k: eng.dev(v) for k, v in f.items()}, clubb)
+    for k in want:
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+    if clubb:                                        # the CLUBB branch accepts a caller without any shallow-scheme field
+        sub = {k: eng.dev(v) for k, v in f.items() if k in ("cmfmc", "qc", "rliq", "cnt", "cnb", "rprddp", "pmid", "rprdtot", "pcnt", "pcnb")}
+        got2 = eng.convect_diagnostics(sub, True)
+        for k in sub:
+            assert np.array_equal(got2[k].cpu().numpy(), want[k]), k
+
+
 @pytest.mark.parametrize("name", cases.ZM_GOLDEN)
 def test_evap_and_momtran_vs_reference_golden(name):
     g = cases.load_golden(name)
