@@ -32,6 +32,9 @@
 #ifndef AERO_SW_WAVES
 #define AERO_SW_WAVES 3                    // bands-outer SW kernel: waves per SIMD the register budget is set for
 #endif
+#ifndef AERO_PRIO
+#define AERO_PRIO 0                       // issue priority of the optics waves (the ZM chain runs at COLPHYS_CHAIN_PRIO)
+#endif
 #ifndef AERO_LW_LDS_CAP_KB
 #define AERO_LW_LDS_CAP_KB 30              // LW: two band groups of 24 KB instead of one of 40 KB: 7 % slower alone, but four
 #endif                                    // blocks then leave 64 KB of a CU's LDS to the ZM chain running beside it (substep -1 %)
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
     constexpr int NOUT = SW ? 4 : 1;
     constexpr int SLICE = aero_slice_doubles(NTAB);
     static_assert(SLICE % 128 == 0, "slice must be whole 1 KiB pieces");
+    __builtin_amdgcn_s_setprio(AERO_PRIO);
     extern __shared__ double smem[];
     double *s_slice0 = smem;                           // two slices (double buffer)
     double *s_acc = smem + 2 * SLICE;                  // [bands_per_group][NOUT][NT]
@@ -312,6 +316,7 @@ __global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(Ae
 {
     constexpr int NTAB = 3;
     constexpr int SLICE = aero_slice_doubles(NTAB);
+    __builtin_amdgcn_s_setprio(AERO_PRIO);
     extern __shared__ double smem[];
     double *s_slice0 = smem;                           // two slices (double buffer)
     double *s_vol = smem + 2 * SLICE + threadIdx.x;    // species volumes [slot][NT], slot = species counted through the modes

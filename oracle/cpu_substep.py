@@ -72,12 +72,16 @@ def _work(rng):
     return _substep(_G["o"], _G["st"], _G["aer"], lo, hi, synth.PHYSCONST, synth.ZTODT, _G["with_aero"])
 
 
-def run_cpu_baseline(st, aer, props, pver, with_aero=True, cores=None, sample_cols=None):
+def run_cpu_baseline(st, aer, props, pver, with_aero=True, cores=None, sample_cols=None, kind=None):
     """Returns dict(value=columns/s, cores, kind, sample, seconds).  Must be called BEFORE the process
-    touches the GPU (workers are forked)."""
+    touches the GPU (workers are forked).  kind: "reference" (oracle/_ref), "port" (the C restatement), or None = the
+    reference build where it is present, else the port."""
     import multiprocessing as mp
     from ref_oracle import have_ref
-    kind = "reference" if have_ref(16, pver) else "port"
+    if kind is None:
+        kind = "reference" if have_ref(16, pver) else "port"
+    if kind == "reference" and not have_ref(16, pver):
+        return None
     ncol = st["ncol"] if sample_cols is None else min(sample_cols, st["ncol"])
     cores = cores or min(16, os.cpu_count() or 1)
     _G.update(st=st, aer=aer, props=props, with_aero=with_aero)
