@@ -142,6 +142,34 @@ __device__ __forceinline__ double cp_log10(double x)
     return dk * log10_2hi + (dk * log10_2lo + __builtin_fma(lm, ivln10_lo, lm * ivln10_hi));
 }
 
+// ---- exp10 ------------------------------------------------------------------------------------------------
+// ROCm OCML's fp64 exp10, operation for operation (constants read from its gfx950 code: n = rint(x log2(10)),
+// r = x - n log10(2) in two pieces, u = r ln(10) in two pieces, degree-11 polynomial, ldexp), WITHOUT its two range
+// guards (x > 1024 -> inf, x < -1075 -> 0: two compares and four selects per call).  Bit-identical to exp10() for
+// |x| < 1024 -- ldexp alone saturates correctly there -- and NaN in, NaN out; the Goff-Gratch exponents it is used for
+// lie in [-12, 9] for any temperature a sounding can hold (T > 100 K).  Larger |x| (T -> 0, garbage input) differ from
+// OCML only in HOW the result is wrong (inf/0 vs a saturated ldexp).
+__device__ __forceinline__ double cp_exp10(double x)
+{
+    const double n = __builtin_rint(x * __longlong_as_double(0x400a934f0979a371LL));
+    double r = __builtin_fma(__longlong_as_double(0xbfd34413509f79ffLL), n, x);
+    r = __builtin_fma(__longlong_as_double(0x3c49dc1da994fd21LL), n, r);
+    double u = r * __longlong_as_double(0xbcaf48ad494ea3e9LL);
+    u = __builtin_fma(__longlong_as_double(0x40026bb1bbb55516LL), r, u);
+    double p = __builtin_fma(u, __longlong_as_double(0x3e5ade156a5dcb37LL), __longlong_as_double(0x3e928af3fca7ab0cLL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3ec71dee623fde64LL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3efa01997c89e6b0LL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3f2a01a014761f6eLL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3f56c16c1852b7b0LL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3f81111111122322LL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3fa55555555502a1LL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3fc5555555555511LL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3fe000000000000bLL));
+    p = __builtin_fma(u, p, 1.0);
+    p = __builtin_fma(u, p, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
 // want_ln ? cp_log(x) : cp_log10(x), bit for bit, from ONE reduction + polynomial: the two lanes of a lane pair
 // (below) evaluate a natural and a decimal logarithm of different arguments in the same instruction stream.
 __device__ __forceinline__ double cp_log_sel(double x, bool want_ln)
@@ -208,17 +236,17 @@ __device__ __forceinline__ double svp_gg_core(double u, double v, bool half, dou
         } else {
             l10u = cp_log10(u);
         }
-        const double ee = exp10(half ? -3.49149 * um1 : 11.344 * (1.0 - v));
+        const double ee = cp_exp10(half ? -3.49149 * um1 : 11.344 * (1.0 - v));
         const double eo = pair_swap(ee);
         e2 = half ? eo : ee;
         e3 = half ? ee : eo;
     } else {
         l10u = cp_log10(u);
         if (WANT_LN) lnval = cp_log(lnarg);
-        e2 = exp10(11.344 * (1.0 - v));
-        e3 = exp10(-3.49149 * um1);
+        e2 = cp_exp10(11.344 * (1.0 - v));
+        e3 = cp_exp10(-3.49149 * um1);
     }
-    return exp10(-7.90298 * um1 + 5.02808 * l10u - 1.3816e-7 * (e2 - 1.0) + 8.1328e-3 * (e3 - 1.0)
+    return cp_exp10(-7.90298 * um1 + 5.02808 * l10u - 1.3816e-7 * (e2 - 1.0) + 8.1328e-3 * (e3 - 1.0)
                  + 3.0057148979490314) * 100.0;        // log10(1013.246), correctly rounded
 }
 __device__ inline double svp_water_gg(double t)
