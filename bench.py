@@ -282,8 +282,8 @@ def main():
                     "note": "path is fp64-transcendental / latency bound, not HBM bound (SURVEY.md 0-4, 8d)",
                     "duration_source": "HIP events on the launch stream in a separate un-overlapped pass after the timed region; "
                                        "rocprofv3 of `bench.py --serial --no-graph` averages the same launches "
-                                       "(profiles/r01_kernel_stats_serial.csv); the default command's rocprofv3 average "
-                                       "(profiles/r01_kernel_stats.csv) also contains the overlapped graph replays"}
+                                       "(profiles/r02_kernel_stats_serial.csv); the default command's rocprofv3 average "
+                                       "(profiles/r02_kernel_stats.csv) also contains the overlapped graph replays"}
         if prof_ov is not None:
             roofline["kernel_ms_overlapped"] = {k: round(v[0], 4) for k, v in prof_ov.items() if v[1] > 0}
         pm = pmc_of(dom) if (args.ncol == 48602 and pver == 32) else None
