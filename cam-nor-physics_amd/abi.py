@@ -106,6 +106,14 @@ class ConvtranIO(C.Structure):
     )
 
 
+DERIVED_FIELDS_IN = ("pint", "lnpint", "t", "q", "qmin", "phis", "cpair", "rair", "zvir")
+DERIVED_FIELDS_OUT = {"pdel": 1, "rpdel": 1, "pmid": 1, "lnpmid": 1, "zi": 2, "zm": 1, "s": 1}
+
+
+class DerivedFieldsIO(C.Structure):
+    _fields_ = [(n, PD) for n in DERIVED_FIELDS_IN + tuple(DERIVED_FIELDS_OUT)]
+
+
 CONVECT_DIAG_FIELDS = ("cmfmc", "qc", "rliq", "cnt", "cnb", "cmfmc2", "qc2", "rprdsh", "rliq2", "cnt2", "cnb2", "precc", "snow",
                        "icwmr", "evapcsh", "rprddp", "pmid", "rprdtot", "pcnt", "pcnb")
 

@@ -448,6 +448,23 @@ int colphys_zm_conv_tend_2_dev(int ncol, int pver, int pcols, int ncnst, double 
     return rc ? fail(rc, "convtran launch failed") : COLPHYS_OK;
 }
 
+int colphys_derived_fields_dev(int ncol, int pver, int ncnst, int dycore_kind, int nspecies, double gravit,
+                               const colphys_derived_fields_io *io, void *stream)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    if (!io) return fail(COLPHYS_ERR_ARG, "null io");
+    if (pver < 2) return fail(COLPHYS_ERR_ARG, "the bottom-layer fix needs two levels");
+    if (dycore_kind < 0 || dycore_kind > 2) return fail(COLPHYS_ERR_ARG, "bad dycore_kind");
+    if (ncnst < 1 || nspecies < 1 || nspecies > ncnst) return fail(COLPHYS_ERR_ARG, "need 1 <= nspecies <= ncnst");
+    const void *need[] = {io->pint, io->lnpint, io->t, io->q, io->qmin, io->phis, io->cpair, io->rair, io->zvir, io->pdel, io->rpdel,
+                          io->pmid, io->lnpmid, io->zi, io->zm, io->s};
+    for (const void *p : need)
+        if (!p) return fail(COLPHYS_ERR_ARG, "null pointer in colphys_derived_fields_io");
+    rc = launch_derived_fields(ncol, pver, ncnst, dycore_kind, nspecies, gravit, *io, (hipStream_t)stream);
+    return rc ? fail(rc, "derived_fields launch failed") : COLPHYS_OK;
+}
+
 int colphys_convect_diagnostics_dev(int ncol, int pver, int shallow_is_clubb, const colphys_convect_diag_io *io, void *stream)
 {
     int rc;

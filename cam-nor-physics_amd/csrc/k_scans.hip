@@ -696,6 +696,82 @@ int launch_convtran(int ncol, int pver, int pcols, int ncnst, const colphys_conv
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
 
+// ---- d_p_coupling derived fields (fv/dp_coupling.F90:550-629), the element-wise parts around geopotential_t ----------
+namespace {
+constexpr int DF_MAXC = 256;
+struct DfQmin { double v[DF_MAXC]; };
+
+__global__ void derived_pressure_kernel(int ncol, int pver, const double *__restrict__ pint, double *__restrict__ pdel,
+                                        double *__restrict__ rpdel, double *__restrict__ pmid, double *__restrict__ lnpmid)
+{
+    const size_t L = (size_t)pver, LP = L + 1, n = (size_t)ncol * L;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const size_t c = i / L, k = i - c * L;
+        const double p0 = pint[c * LP + k], p1 = pint[c * LP + k + 1];
+        const double dp = p1 - p0;                                               // :554
+        pdel[i] = dp;
+        rpdel[i] = 1.0 / dp;                                                     // :555
+        const double pm = 0.5 * (p0 + p1);                                       // :556
+        pmid[i] = pm;
+        lnpmid[i] = cp_log(pm);                                                  // :557
+    }
+}
+
+// bottom-layer fix (:565-590): one thread per (constituent, column); pdel from pint so that the kernel does not depend on
+// the kernel above having finished for other columns
+__global__ void derived_qfix_kernel(int ncol, int pver, int m0, int nm, DfQmin qmin, const double *__restrict__ pint, double *q)
+{
+    const size_t L = (size_t)pver, LP = L + 1, F = (size_t)ncol * L;
+    const size_t n = (size_t)nm * ncol, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const size_t mm = i / ncol, c = i - mm * ncol;
+        double *qc = q + (m0 + mm) * F + c * L;
+        const double qm = qmin.v[mm];
+        const double qbot = qc[pver - 1];
+        if (qbot < qm) {
+            const double *pc = pint + c * LP;
+            const double pdel_bot = pc[pver] - pc[pver - 1], pdel_m1 = pc[pver - 1] - pc[pver - 2];
+            const double qmavl = qc[pver - 2] - qm;                              // :569
+            const double dqreq = (qm - qbot) * pdel_bot / pdel_m1;               // :571-572
+            if (dqreq < qmavl) {                                                 // :575-577
+                qc[pver - 1] = qm;
+                qc[pver - 2] = qc[pver - 2] - dqreq;
+            }
+        }
+    }
+}
+
+__global__ void derived_dse_kernel(int ncol, int pver, double gravit, const double *__restrict__ cpair, const double *__restrict__ t,
+                                   const double *__restrict__ zm, const double *__restrict__ phis, double *__restrict__ s)
+{
+    const size_t L = (size_t)pver, n = (size_t)ncol * L, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        s[i] = cpair[i] * t[i] + gravit * zm[i] + phis[i / L];                   // :626-627
+}
+}  // namespace
+
+int launch_derived_fields(int ncol, int pver, int ncnst, int dycore_kind, int nspecies, double gravit,
+                          const colphys_derived_fields_io &io, hipStream_t st)
+{
+    const size_t n = (size_t)ncol * pver;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(derived_pressure_kernel, dim3(blocks), dim3(256), 0, st, ncol, pver, io.pint, io.pdel, io.rpdel, io.pmid, io.lnpmid);
+    for (int m0 = 0; m0 < ncnst; m0 += DF_MAXC) {
+        DfQmin qm;
+        const int nm = ncnst - m0 < DF_MAXC ? ncnst - m0 : DF_MAXC;
+        for (int m = 0; m < nm; ++m) qm.v[m] = io.qmin[m0 + m];
+        const size_t nq = (size_t)nm * ncol;
+        const int bq = (int)((nq + 255) / 256 < 4096 ? (nq + 255) / 256 : 4096);
+        hipLaunchKernelGGL(derived_qfix_kernel, dim3(bq), dim3(256), 0, st, ncol, pver, m0, nm, qm, io.pint, io.q);
+    }
+    int rc = launch_geopotential_t(ncol, pver, dycore_kind, ncnst, nspecies, io.lnpint, io.pint, io.pmid, io.pdel, io.rpdel, io.t, io.q,
+                                   io.rair, gravit, io.zvir, io.zi, io.zm, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(derived_dse_kernel, dim3(blocks), dim3(256), 0, st, ncol, pver, gravit, io.cpair, io.t, io.zm, io.phis, io.s);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}
+
 // ---- convect_diagnostics_calc (convect_diagnostics.F90:115-249): element-wise merge, grid-stride ------------------
 namespace {
 __global__ void convect_diag_kernel(int ncol, int pver, int clubb, colphys_convect_diag_io io)

@@ -58,7 +58,7 @@ EXPORTED_SYMBOLS = [
     "colphys_zm_conv_evap_dev", "colphys_zm_conv_evap_chunks",
     "colphys_momtran_dev", "colphys_momtran_chunks",
     "colphys_convtran_dev", "colphys_convtran_chunks", "colphys_physics_update_dev", "colphys_zm_conv_tend_dev",
-    "colphys_zm_conv_tend_2_dev", "colphys_convect_diagnostics_dev",
+    "colphys_zm_conv_tend_2_dev", "colphys_convect_diagnostics_dev", "colphys_derived_fields_dev",
     "colphys_aero_tables_set",
     "colphys_modal_aero_sw_dev", "colphys_modal_aero_lw_dev",
     "colphys_modal_aero_sw_chunks", "colphys_modal_aero_lw_chunks",
@@ -266,6 +266,21 @@ class ColumnPhysics:
         self._check(self.lib.colphys_zm_conv_tend_2_dev(C.c_int(n), C.c_int(pver), C.c_int(pcols), C.c_int(ncnst),
                                                         C.c_double(ztodt), C.byref(io), self._stream()))
         return ptend_q
+
+    # ---- d_p_coupling derived fields (fv/dp_coupling.F90:550-629) ---------------------------------------
+    def derived_fields(self, pint, lnpint, t, q, qmin, phis, cpair, rair, zvir, gravit, dycore=abi.DYCORE_FV, nspecies=1):
+        """q: [ncnst][ncol][pver], fixed in place; qmin: host sequence of ncnst; returns the seven derived fields"""
+        ncnst, n, pver = q.shape
+        shape = {1: (n, pver), 2: (n, pver + 1)}
+        out = {k: self.empty(*shape[lv]) for k, lv in abi.DERIVED_FIELDS_OUT.items()}
+        io = abi.DerivedFieldsIO()
+        qm = np.ascontiguousarray(qmin, dtype=np.float64)
+        for k, v in dict(pint=pint, lnpint=lnpint, t=t, q=q, phis=phis, cpair=cpair, rair=rair, zvir=zvir, **out).items():
+            setattr(io, k, _p(self._f64(v)))
+        io.qmin = abi.dptr(qm)
+        self._check(self.lib.colphys_derived_fields_dev(C.c_int(n), C.c_int(pver), C.c_int(ncnst), C.c_int(dycore), C.c_int(nspecies),
+                                                        C.c_double(gravit), C.byref(io), self._stream()))
+        return out
 
     # ---- convect_diagnostics_calc (convect_diagnostics.F90:115-249) --------------------------------------
     def convect_diagnostics(self, fields: dict, shallow_is_clubb: bool):

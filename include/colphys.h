@@ -16,6 +16,7 @@
  *   colphys_momtran*                 momtran                  physics/zm_conv.F90:2315-2715
  *   colphys_convtran*                convtran                 physics/zm_conv.F90:1976-2311
  *   colphys_convect_diagnostics_dev  convect_diagnostics_calc physics/convect_diagnostics.F90:115-249
+ *   colphys_derived_fields_dev       d_p_coupling, 'derived_fields' block   fv/dp_coupling.F90:550-625
  *   colphys_zm_conv_tend_2_dev       zm_conv_tend_2           physics/zm_conv_intr.F90:955-1028 (and the convtran1
  *                                    step of zm_conv_tend, :860-884) on resident data
  *   colphys_aero_tables_set          rad_cnst_get_mode_props / rad_cnst_get_aer_props data consumed at
@@ -252,6 +253,34 @@ typedef struct colphys_zm_conv_tend_2_io {
 
 int colphys_zm_conv_tend_2_dev(int ncol, int pver, int pcols, int ncnst, double ztodt, const colphys_zm_conv_tend_2_io *io,
                                void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * d_p_coupling's derived fields  (fv/dp_coupling.F90:550-625): what the dynamics-physics coupler derives
+ * from pint / T / q before physics runs, on resident data, so that the fields the ZM path consumes are produced on the
+ * device:
+ *     pdel = pint(k+1) - pint(k), rpdel = 1/pdel, pmid = (pint(k) + pint(k+1))/2, lnpmid = log(pmid)      :552-559
+ *     bottom-layer fix of negative constituents, every m: if q(pver,m) < qmin(m) and the level above can pay,
+ *         q(pver,m) = qmin(m), q(pver-1,m) -= (qmin(m) - q(pver,m)) pdel(pver)/pdel(pver-1)               :565-590
+ *     geopotential_t(lnpint, lnpmid, pint, pmid, pdel, rpdel, t, q, rairv, gravit, zvirv) -> zi, zm        :617-621
+ *     s = cpairv t + gravit zm + phis                                                                      :624-629
+ * q is [ncnst][ncol][pver], in/out; qmin a HOST array of ncnst lower bounds (constituents' qmin).
+ * Not included (host / upstream code): physics_cnst_limit, cam_thermo_dry_air_update, set_state_pdry / set_wet_to_dry,
+ * qneg3, check_energy_timestep_init (:593-651).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct colphys_derived_fields_io {
+    const double *pint, *lnpint;                     /* [ncol][pver+1] */
+    const double *t;                                 /* [ncol][pver]   */
+    double *q;                                       /* [ncnst][ncol][pver] in/out */
+    const double *qmin;                              /* HOST [ncnst]   */
+    const double *phis;                              /* [ncol]         */
+    const double *cpair, *rair, *zvir;               /* [ncol][pver]: cpairv, rairv, zvirv */
+    double *pdel, *rpdel, *pmid, *lnpmid;            /* [ncol][pver]   out */
+    double *zi;                                      /* [ncol][pver+1] out */
+    double *zm, *s;                                  /* [ncol][pver]   out */
+} colphys_derived_fields_io;
+
+int colphys_derived_fields_dev(int ncol, int pver, int ncnst, int dycore_kind, int nspecies, double gravit,
+                               const colphys_derived_fields_io *io, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * convect_diagnostics_calc  (convect_diagnostics.F90:115-249): merges the deep scheme's outputs with the shallow scheme's

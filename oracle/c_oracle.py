@@ -49,6 +49,21 @@ class COracle:
         return zi, zm
 
     # --------------------------------------------------------------------------------------------
+    def derived_fields(self, pint, lnpint, t, q, qmin, phis, cpair, rair, zvir, gravit, dycore=1, nspecies=1):
+        """q [ncnst][ncol][pver] is fixed in place; returns the seven derived fields"""
+        ncnst, n, pver = q.shape
+        assert q.dtype == np.float64 and q.flags["C_CONTIGUOUS"]
+        out = {k: np.zeros((n, pver + (1 if lv == 2 else 0))) for k, lv in abi.DERIVED_FIELDS_OUT.items()}
+        keep = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in dict(pint=pint, lnpint=lnpint, t=t, qmin=qmin, phis=phis,
+                                                                              cpair=cpair, rair=rair, zvir=zvir).items()}
+        io = abi.DerivedFieldsIO()
+        for k, v in {**keep, "q": q, **out}.items():
+            setattr(io, k, abi.dptr(v))
+        self.lib.oracle_derived_fields(C.c_int(n), C.c_int(pver), C.c_int(ncnst), C.c_int(dycore), C.c_int(nspecies),
+                                       C.c_double(gravit), C.byref(io))
+        return out
+
+    # --------------------------------------------------------------------------------------------
     def convect_diagnostics(self, fields: dict, shallow_is_clubb: bool):
         """fields: numpy arrays named as abi.CONVECT_DIAG_FIELDS (missing = NULL); in/out arrays are updated in place"""
         n, pver = fields["qc"].shape

@@ -1521,3 +1521,39 @@ void oracle_convect_diagnostics(int ncol, int pver, int clubb, const colphys_con
         io->rliq[i] = io->rliq[i] + (clubb ? 0.0 : io->rliq2[i]);               /* :231 */
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * d_p_coupling, 'derived_fields' block  /root/reference/fv/dp_coupling.F90:550-629
+ * (no reference build: the routine lives in the FV dynamics-physics coupler; line-by-line restatement of :552-559,
+ *  :565-590, :617-629, checked in tests/ against an independent array-form restatement)
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_derived_fields(int ncol, int pver, int ncnst, int dycore_kind, int nspecies, double gravit,
+                           const colphys_derived_fields_io *io)
+{
+    const size_t L = (size_t)pver, LP = L + 1, F = (size_t)ncol * L;
+    for (int i = 0; i < ncol; ++i) {
+        for (int k = 0; k < pver; ++k) {
+            const double p0 = io->pint[i * LP + k], p1 = io->pint[i * LP + k + 1];
+            io->pdel[i * L + k] = p1 - p0;
+            io->rpdel[i * L + k] = 1.0 / io->pdel[i * L + k];
+            io->pmid[i * L + k] = 0.5 * (p0 + p1);
+            io->lnpmid[i * L + k] = log(io->pmid[i * L + k]);
+        }
+        for (int m = 0; m < ncnst; ++m) {
+            double *qc = io->q + m * F + i * L;
+            if (qc[pver - 1] < io->qmin[m]) {
+                const double qmavl = qc[pver - 2] - io->qmin[m];
+                const double dqreq = (io->qmin[m] - qc[pver - 1]) * io->pdel[i * L + pver - 1] / io->pdel[i * L + pver - 2];
+                if (dqreq < qmavl) {
+                    qc[pver - 1] = io->qmin[m];
+                    qc[pver - 2] = qc[pver - 2] - dqreq;
+                }
+            }
+        }
+    }
+    oracle_geopotential_t(ncol, pver, dycore_kind, ncnst, nspecies, io->lnpint, io->lnpmid, io->pint, io->pmid, io->pdel, io->rpdel,
+                          io->t, io->q, io->rair, gravit, io->zvir, io->zi, io->zm);
+    for (int i = 0; i < ncol; ++i)
+        for (int k = 0; k < pver; ++k)
+            io->s[i * L + k] = io->cpair[i * L + k] * io->t[i * L + k] + gravit * io->zm[i * L + k] + io->phis[i];
+}

@@ -19,6 +19,8 @@ extern "C" {
 
 void oracle_init(const colphys_zm_params *p);
 
+void oracle_derived_fields(int ncol, int pver, int ncnst, int dycore_kind, int nspecies, double gravit,
+                           const colphys_derived_fields_io *io);
 void oracle_convect_diagnostics(int ncol, int pver, int clubb, const colphys_convect_diag_io *io);
 void oracle_geopotential_dse(int ncol, int pver, int dycore_kind, int nq, int nspecies, const double *piln,
                              const double *pmln, const double *pint, const double *pmid, const double *pdel,

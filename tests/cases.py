@@ -161,3 +161,43 @@ def convect_diag_numpy(f, clubb):
     o["qc"] = o["qc"] + o["qc2"]
     o["rliq"] = o["rliq"] + o["rliq2"]
     return o
+
+
+def derived_fields_case(ncol, pver, ncnst, seed):
+    """Inputs of d_p_coupling's derived-fields block: interface pressures, T, constituents with some negative bottom-layer
+    values (both outcomes of the fix: payable by the level above or not), constituent-dependent cpairv / rairv."""
+    st = synth.make_state(ncol, pver, seed)
+    c = synth.PHYSCONST
+    rng = np.random.default_rng(seed + 17)
+    q = np.empty((ncnst, ncol, pver))
+    q[0] = st["q"]
+    for m in range(1, ncnst):
+        q[m] = rng.uniform(0.0, 1.0e-6, (ncol, pver))
+    neg = rng.uniform(size=(ncnst, ncol)) < 0.15
+    q[:, :, -1] = np.where(neg, -rng.uniform(0.0, 2.0e-7, (ncnst, ncol)), q[:, :, -1])
+    poor = rng.uniform(size=(ncnst, ncol)) < 0.3                       # level above cannot pay
+    q[:, :, -2] = np.where(neg & poor, 1.0e-12, q[:, :, -2])
+    qmin = np.full(ncnst, 0.0); qmin[0] = 1.0e-12
+    cpair = c["cpair"] * (1.0 + 0.01 * rng.uniform(-1, 1, (ncol, pver)))
+    return dict(pint=st["pint"], lnpint=st["lnpint"], t=st["t"], q=np.ascontiguousarray(q), qmin=qmin, phis=st["phis"], cpair=cpair,
+                rair=st["rair"], zvir=st["zvir"], gravit=c["gravit"])
+
+
+def derived_fields_numpy(a, geo_oracle, dycore, nspecies):
+    """Independent array-form restatement of fv/dp_coupling.F90:552-559, 565-590, 617-629 (geopotential_t from `geo_oracle`)"""
+    pint, q = a["pint"], a["q"].copy()
+    pdel = pint[:, 1:] - pint[:, :-1]
+    rpdel = 1.0 / pdel
+    pmid = 0.5 * (pint[:, :-1] + pint[:, 1:])
+    lnpmid = np.log(pmid)
+    for m in range(q.shape[0]):
+        bot, up = q[m, :, -1], q[m, :, -2]
+        need = bot < a["qmin"][m]
+        dqreq = (a["qmin"][m] - bot) * pdel[:, -1] / pdel[:, -2]
+        ok = need & (dqreq < up - a["qmin"][m])
+        q[m, :, -2] = np.where(ok, up - dqreq, up)
+        q[m, :, -1] = np.where(ok, a["qmin"][m], bot)
+    zi, zm = geo_oracle.geopotential_t(a["lnpint"], lnpmid, pint, pmid, pdel, rpdel, a["t"], q, a["rair"], a["gravit"], a["zvir"],
+                                       dycore=dycore, nspecies=nspecies)
+    s = a["cpair"] * a["t"] + a["gravit"] * zm + a["phis"][:, None]
+    return dict(pdel=pdel, rpdel=rpdel, pmid=pmid, lnpmid=lnpmid, zi=zi, zm=zm, s=s, q=q)

@@ -63,6 +63,23 @@ def test_geopotential_dse_vs_reference_golden(pver):
         assert np.max(np.abs(t - t_true) / t_true) < 1e-12, tag
 
 
+@pytest.mark.parametrize("dycore,nspecies", [(abi.DYCORE_FV, 1), (abi.DYCORE_SE, 2), (abi.DYCORE_EUL, 1)])
+def test_derived_fields_restatement_against_array_form(dycore, nspecies):
+    """d_p_coupling's derived-fields block lives in the FV coupler, which cannot be built from the reference alone: the C
+    restatement is checked against an independent array-form restatement (geopotential_t itself is pinned to the reference
+    build by the goldens)."""
+    a = cases.derived_fields_case(257, 32, 5, 3)
+    co = COracle(cases.default_params(32))
+    want = cases.derived_fields_numpy(a, co, dycore, nspecies)
+    q = a["q"].copy()
+    got = co.derived_fields(a["pint"], a["lnpint"], a["t"], q, a["qmin"], a["phis"], a["cpair"], a["rair"], a["zvir"], a["gravit"],
+                            dycore=dycore, nspecies=nspecies)
+    got["q"] = q
+    assert (want["q"] != a["q"]).any() and (want["q"][:, :, -1] < a["qmin"][:, None]).any()      # both outcomes of the fix occur
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+
+
 @pytest.mark.parametrize("clubb", [True, False])
 def test_convect_diagnostics_restatement_against_array_form(clubb):
     """convect_diagnostics_calc cannot be built from the reference alone (it needs the parent model's physics_types /

@@ -122,6 +122,28 @@ def test_geopotential_dse_full_size_round_trip():
     assert float(((zm2 - zm).abs().max(dim=1).values / zm.abs().max(dim=1).values).max()) < 1e-12
 
 
+@pytest.mark.parametrize("ncol,pver,ncnst,dycore,nspecies", [(1003, 32, 5, abi.DYCORE_FV, 1), (48602, 32, 3, abi.DYCORE_FV, 1),
+                                                             (333, 70, 7, abi.DYCORE_SE, 2), (64, 26, 300, abi.DYCORE_EUL, 1)])
+def test_derived_fields_vs_c_oracle(ncol, pver, ncnst, dycore, nspecies):
+    """d_p_coupling's derived fields on resident data: pressures, bottom-layer fix, heights and dry static energy are the
+    oracle's bit for bit; log(pmid) is the device logarithm (< 1 ulp class): 1e-10 relative as everywhere else."""
+    from c_oracle import COracle
+    a = cases.derived_fields_case(ncol, pver, ncnst, 11 + ncol)
+    params = cases.default_params(pver)
+    qw = a["q"].copy()
+    want = COracle(params).derived_fields(a["pint"], a["lnpint"], a["t"], qw, a["qmin"], a["phis"], a["cpair"], a["rair"], a["zvir"],
+                                          a["gravit"], dycore=dycore, nspecies=nspecies)
+    eng = engine(params)
+    d = eng.dev
+    qg = d(a["q"])
+    got = eng.derived_fields(d(a["pint"]), d(a["lnpint"]), d(a["t"]), qg, a["qmin"], d(a["phis"]), d(a["cpair"]), d(a["rair"]), d(a["zvir"]),
+                             a["gravit"], dycore=dycore, nspecies=nspecies)
+    assert np.array_equal(qg.cpu().numpy(), qw)
+    for k in ("pdel", "rpdel", "pmid", "zi", "zm", "s"):
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+    assert_close("lnpmid", got["lnpmid"].cpu().numpy(), want["lnpmid"])
+
+
 @pytest.mark.parametrize("clubb", [True, False])
 @pytest.mark.parametrize("ncol,pver", [(1003, 32), (48602, 32), (257, 70)])
 def test_convect_diagnostics_vs_c_oracle(ncol, pver, clubb):
