@@ -139,10 +139,19 @@ def main():
     from cam_nor_physics_amd import abi
     from cam_nor_physics_amd.engine import ColumnPhysics
 
+    # Rehearsal switches (tests/test_bench_multirank_gpu.py: N ranks on ONE GPU): COLPHYS_BENCH_BACKEND=gloo swaps RCCL for
+    # gloo (RCCL refuses two ranks on one device), COLPHYS_BENCH_SHARE_GPU=1 puts every rank on device 0.  The real
+    # launch (one process per GPU, backend "nccl" = RCCL) sets neither.
+    backend = os.environ.get("COLPHYS_BENCH_BACKEND", "nccl")
+    if os.environ.get("COLPHYS_BENCH_SHARE_GPU", "0") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     params = abi.make_zm_params(synth.PHYSCONST, synth.ZM_NAMELIST, synth.limcnv_from_pref(pver))
     eng = ColumnPhysics(params, local_rank)
     c = synth.PHYSCONST
@@ -221,6 +230,8 @@ def main():
     el = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
     cols = torch.tensor([float(ncol)], dtype=torch.float64, device=eng.device)
     if world > 1:
+        if backend != "nccl":                       # gloo reduces host tensors
+            el, cols = el.cpu(), cols.cpu()
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(cols, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
