@@ -36,6 +36,13 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own HIP runtime, and the process must hold ONE.  Loading this library before torch binds it
+    # to /opt/rocm's runtime, and a later `import torch` then initialises a second one that owns the device
+    # (colphys_init: "no HIP device") -- seen with build() followed by smoke() in one process.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = os.environ.get("COLPHYS_LIB", LIB)          # COLPHYS_LIB: A/B experiment builds only
     if not os.path.exists(path):
         if build_if_missing and path == LIB:
