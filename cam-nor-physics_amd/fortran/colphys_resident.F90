@@ -1,0 +1,223 @@
+! colphys_resident -- Fortran host side of the WHOLE-NODE dispatch (BASELINE north star: "host code stays Fortran").
+!
+! The per-chunk shim (zm_conv_hip.F90 ...) copies every argument to the device and back on each call.  This module is the
+! other half of the design: a rank's physics_state / pbuf fields are uploaded ONCE per physics step into column-contiguous
+! SoA device buffers ([column][level], include/colphys.h), the resident-data entry points of the C ABI (colphys_*_dev)
+! run on them -- zm_conv_tend (zm_conv_intr.F90:441-905) is ONE call for all chunks of the rank -- and only what the host
+! needs comes back.  Device memory and copies go through the HIP runtime's C entry points (bind(C) below): no wrapper
+! library, no CUDA-compatibility layer.
+!
+! Layout contract.  Host arrays are CAM's: (pcols, nlev, nchunks), columns 1:ncol(c) of chunk c valid, the rest padding
+! (+inf in CAM, physics_types.F90:2143-2178).  Device row r = (c-1)*pcols + i - 1 holds column i of chunk c; padding rows
+! shadow column 1 of their chunk (finite, and they convect exactly when it does), so the kernels never see +inf and the
+! gathered sets are trimmed back to the valid columns on download (colphys_download_gathered_sets).
+module colphys_resident
+  use iso_c_binding
+  use colphys_c_api
+  implicit none
+  private
+  save
+
+  integer, parameter :: r8 = c_double
+  integer(c_int), parameter :: hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2
+
+  type, public :: colphys_field                     ! one device buffer [nrows][nlev]
+     type(c_ptr) :: d = c_null_ptr
+     integer :: nlev = 0
+     integer :: nrows = 0
+  end type colphys_field
+
+  ! include/colphys.h: colphys_zm_conv_tend_io (field order = the header's)
+  type, bind(C), public :: colphys_zm_conv_tend_io
+     type(c_ptr) :: t, q, u, v, pmid, pint, pdel, rpdel, lnpint, lnpmid, zm, zi
+     type(c_ptr) :: phis, ps
+     type(c_ptr) :: rair, zvir
+     type(c_ptr) :: pblh, tpert, landfrac
+     type(c_ptr) :: cld
+     type(c_ptr) :: ptend_s, ptend_q, ptend_u, ptend_v
+     type(c_ptr) :: prec, snow, rliq, rice, jctop, jcbot, cape
+     type(c_ptr) :: ql, rprd, evapcdp, dlf
+     type(c_ptr) :: mconzm, flxprec, flxsnow
+     type(c_ptr) :: mu, md, du, eu, ed, dp, dsubcld
+     type(c_ptr) :: jt, maxg, ideep, lengath
+     type(c_ptr) :: freqzm, pcont, pconb
+     type(c_ptr) :: mu_out, md_out
+     type(c_ptr) :: t1, q1, u1, v1, zi1, zm1
+     type(c_ptr) :: status
+  end type colphys_zm_conv_tend_io
+
+  ! include/colphys.h: colphys_zm_conv_tend_2_io
+  type, bind(C), public :: colphys_zm_conv_tend_2_io
+     type(c_ptr) :: q, fracis, pdeldry, mu, md, du, eu, ed, dp
+     type(c_ptr) :: jt, maxg, ideep, lq, isdry
+     type(c_ptr) :: ptend_q
+  end type colphys_zm_conv_tend_2_io
+
+  interface
+     integer(c_int) function hipMalloc(ptr, bytes) bind(C, name='hipMalloc')
+       import
+       type(c_ptr), intent(out) :: ptr
+       integer(c_size_t), value :: bytes
+     end function
+     integer(c_int) function hipFree(ptr) bind(C, name='hipFree')
+       import
+       type(c_ptr), value :: ptr
+     end function
+     integer(c_int) function hipMemcpy(dst, src, bytes, kind) bind(C, name='hipMemcpy')
+       import
+       type(c_ptr), value :: dst, src
+       integer(c_size_t), value :: bytes
+       integer(c_int), value :: kind
+     end function
+     integer(c_int) function hipDeviceSynchronize() bind(C, name='hipDeviceSynchronize')
+       import
+     end function
+     integer(c_int) function colphys_zm_conv_tend_dev(ncol, pver, pcols, ztodt, dycore_kind, qmin, io, stream) &
+          bind(C, name='colphys_zm_conv_tend_dev')
+       import
+       integer(c_int), value :: ncol, pver, pcols, dycore_kind
+       real(c_double), value :: ztodt, qmin
+       type(colphys_zm_conv_tend_io), intent(in) :: io
+       type(c_ptr), value :: stream
+     end function
+     integer(c_int) function colphys_zm_conv_tend_2_dev(ncol, pver, pcols, ncnst, ztodt, io, stream) &
+          bind(C, name='colphys_zm_conv_tend_2_dev')
+       import
+       integer(c_int), value :: ncol, pver, pcols, ncnst
+       real(c_double), value :: ztodt
+       type(colphys_zm_conv_tend_2_io), intent(in) :: io
+       type(c_ptr), value :: stream
+     end function
+  end interface
+
+  public :: colphys_zm_conv_tend_dev, colphys_zm_conv_tend_2_dev
+  public :: colphys_alloc, colphys_alloc_int, colphys_release, colphys_upload, colphys_upload_multi, colphys_download, &
+            colphys_download_int, colphys_download_gathered_sets, colphys_sync
+
+contains
+
+  subroutine check(rc, what)
+    use cam_abortutils, only: endrun
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: what
+    if (rc /= 0) call endrun('colphys_resident: '//what//' failed')
+  end subroutine check
+
+  subroutine colphys_alloc(f, nrows, nlev)          ! fp64 field
+    type(colphys_field), intent(inout) :: f
+    integer, intent(in) :: nrows, nlev
+    call check(hipMalloc(f%d, int(nrows, c_size_t) * int(nlev, c_size_t) * 8_c_size_t), 'hipMalloc')
+    f%nrows = nrows; f%nlev = nlev
+  end subroutine colphys_alloc
+
+  subroutine colphys_alloc_int(f, nrows)            ! int32 per-row field
+    type(colphys_field), intent(inout) :: f
+    integer, intent(in) :: nrows
+    call check(hipMalloc(f%d, int(nrows, c_size_t) * 4_c_size_t), 'hipMalloc')
+    f%nrows = nrows; f%nlev = 1
+  end subroutine colphys_alloc_int
+
+  subroutine colphys_release(f)
+    type(colphys_field), intent(inout) :: f
+    if (c_associated(f%d)) call check(hipFree(f%d), 'hipFree')
+    f%d = c_null_ptr; f%nrows = 0; f%nlev = 0
+  end subroutine colphys_release
+
+  subroutine colphys_sync()
+    call check(hipDeviceSynchronize(), 'hipDeviceSynchronize')
+  end subroutine colphys_sync
+
+  ! host (pcols, nlev, nchunks) -> device [nchunks*pcols][nlev]; padding rows shadow column 1 of their chunk
+  subroutine colphys_upload(f, host, pcols, nlev, nchunks, ncol)
+    type(colphys_field), intent(inout) :: f
+    integer, intent(in) :: pcols, nlev, nchunks, ncol(nchunks)
+    real(r8), intent(in) :: host(pcols, nlev, nchunks)
+    real(r8), allocatable, target :: tmp(:,:)
+    integer :: c, i, isrc
+    if (.not. c_associated(f%d)) call colphys_alloc(f, nchunks*pcols, nlev)
+    allocate(tmp(nlev, nchunks*pcols))
+    do c = 1, nchunks
+       do i = 1, pcols
+          isrc = merge(i, 1, i <= ncol(c))
+          tmp(:, (c-1)*pcols + i) = host(isrc, :, c)
+       end do
+    end do
+    call check(hipMemcpy(f%d, c_loc(tmp), int(size(tmp), c_size_t) * 8_c_size_t, hipMemcpyHostToDevice), 'hipMemcpy (upload)')
+  end subroutine colphys_upload
+
+  ! nf fields at once, host (pcols, nlev, nf, nchunks) as CAM keeps constituents -> device [nf][nchunks*pcols][nlev]
+  subroutine colphys_upload_multi(f, host, pcols, nlev, nf, nchunks, ncol)
+    type(colphys_field), intent(inout) :: f
+    integer, intent(in) :: pcols, nlev, nf, nchunks, ncol(nchunks)
+    real(r8), intent(in) :: host(pcols, nlev, nf, nchunks)
+    real(r8), allocatable, target :: tmp(:,:,:)
+    integer :: c, i, m, isrc
+    if (.not. c_associated(f%d)) call colphys_alloc(f, nf*nchunks*pcols, nlev)
+    allocate(tmp(nlev, nchunks*pcols, nf))
+    do c = 1, nchunks
+       do m = 1, nf
+          do i = 1, pcols
+             isrc = merge(i, 1, i <= ncol(c))
+             tmp(:, (c-1)*pcols + i, m) = host(isrc, :, m, c)
+          end do
+       end do
+    end do
+    call check(hipMemcpy(f%d, c_loc(tmp), int(size(tmp), c_size_t) * 8_c_size_t, hipMemcpyHostToDevice), 'hipMemcpy (upload)')
+  end subroutine colphys_upload_multi
+
+  ! device [nchunks*pcols][nlev] -> host (pcols, nlev, nchunks), the first nvalid(c) columns of each chunk
+  subroutine colphys_download(f, host, pcols, nlev, nchunks, nvalid)
+    type(colphys_field), intent(in) :: f
+    integer, intent(in) :: pcols, nlev, nchunks, nvalid(nchunks)
+    real(r8), intent(inout) :: host(pcols, nlev, nchunks)
+    real(r8), allocatable, target :: tmp(:,:)
+    integer :: c, i
+    allocate(tmp(nlev, nchunks*pcols))
+    call check(hipMemcpy(c_loc(tmp), f%d, int(size(tmp), c_size_t) * 8_c_size_t, hipMemcpyDeviceToHost), 'hipMemcpy (download)')
+    do c = 1, nchunks
+       do i = 1, nvalid(c)
+          host(i, :, c) = tmp(:, (c-1)*pcols + i)
+       end do
+    end do
+  end subroutine colphys_download
+
+  subroutine colphys_download_int(f, host, pcols, nchunks, nvalid)
+    type(colphys_field), intent(in) :: f
+    integer, intent(in) :: pcols, nchunks, nvalid(nchunks)
+    integer, intent(inout) :: host(pcols, nchunks)
+    integer(c_int32_t), allocatable, target :: tmp(:)
+    integer :: c, i
+    allocate(tmp(nchunks*pcols))
+    call check(hipMemcpy(c_loc(tmp), f%d, int(size(tmp), c_size_t) * 4_c_size_t, hipMemcpyDeviceToHost), 'hipMemcpy (download)')
+    do c = 1, nchunks
+       do i = 1, nvalid(c)
+          host(i, c) = tmp((c-1)*pcols + i)
+       end do
+    end do
+  end subroutine colphys_download_int
+
+  ! lengath / ideep as zm_convr returns them per chunk (zm_conv.F90:905-940), with the shadow (padding) columns -- which
+  ! sit at the tail of a chunk's ascending ideep list -- dropped: lengath(c) = count(ideep(1:len,c) <= ncol(c))
+  subroutine colphys_download_gathered_sets(f_ideep, f_lengath, ideep, lengath, pcols, nchunks, ncol)
+    type(colphys_field), intent(in) :: f_ideep, f_lengath
+    integer, intent(in) :: pcols, nchunks, ncol(nchunks)
+    integer, intent(out) :: ideep(pcols, nchunks), lengath(nchunks)
+    integer(c_int32_t), allocatable, target :: tmp(:), len(:)
+    integer :: c, j, n
+    allocate(tmp(nchunks*pcols), len(nchunks))
+    call check(hipMemcpy(c_loc(tmp), f_ideep%d, int(size(tmp), c_size_t) * 4_c_size_t, hipMemcpyDeviceToHost), 'hipMemcpy (ideep)')
+    call check(hipMemcpy(c_loc(len), f_lengath%d, int(nchunks, c_size_t) * 4_c_size_t, hipMemcpyDeviceToHost), 'hipMemcpy (lengath)')
+    ideep = 0
+    do c = 1, nchunks
+       n = 0
+       do j = 1, len(c)
+          if (tmp((c-1)*pcols + j) <= ncol(c)) then
+             n = n + 1
+             ideep(n, c) = tmp((c-1)*pcols + j)
+          end if
+       end do
+       lengath(c) = n
+    end do
+  end subroutine colphys_download_gathered_sets
+
+end module colphys_resident
