@@ -78,6 +78,28 @@ def pmc_of(kernel):
     return None
 
 
+def valu_issue_of_substep(ms_per_step, with_aero):
+    """Substep-level fp64 VALU issue figure from the committed PMC passes: sum over the substep's launches of the wave-level
+    VALU instructions (SQ_INSTS_VALU) x 4 cycles (one fp64 instruction per SIMD per 4 cycles, scripts/ubench) over
+    1 024 SIMDs at the 2.4 GHz peak clock, as a fraction of the measured step time -- what bounds this path beside the HBM
+    fraction the contract asks for."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")))
+    if not files:
+        return None
+    mult = {"geopotential_kernel": 3, "physics_update_kernel": 3}
+    total = 0.0
+    for r in csv.DictReader(open(files[-1])):
+        k = r["kernel"]
+        if not r.get("SQ_INSTS_VALU") or (not with_aero and k.startswith("modal_aero")):
+            continue
+        total += float(r["SQ_INSTS_VALU"]) * mult.get(k, 1)
+    ms_bound = total * 4.0 / (1024 * 2.4e9) * 1e3
+    return {"wave_valu_instructions": round(total), "ms_at_full_issue": round(ms_bound, 4), "frac_of_step": round(ms_bound / ms_per_step, 4),
+            "source": os.path.basename(files[-1])}
+
+
 def baseline_metric():
     try:
         with open(os.path.join(ROOT, "BASELINE.json")) as f:
@@ -295,6 +317,10 @@ def main():
                                        "rocprofv3 of `bench.py --serial --no-graph` averages the same launches "
                                        "(profiles/r02_kernel_stats_serial.csv); the default command's rocprofv3 average "
                                        "(profiles/r02_kernel_stats.csv) also contains the overlapped graph replays"}
+        if args.ncol == 48602 and pver == 32:
+            vi = valu_issue_of_substep(ms_per_step, with_aero)
+            if vi is not None:
+                roofline["valu_issue"] = vi
         if prof_ov is not None:
             roofline["kernel_ms_overlapped"] = {k: round(v[0], 4) for k, v in prof_ov.items() if v[1] > 0}
         pm = pmc_of(dom) if (args.ncol == 48602 and pver == 32) else None

@@ -16,7 +16,7 @@ NCOEF, PREFR, PREFI = 5, 7, 10
 
 K_GEOPOTENTIAL, K_ZM_TRIGGER, K_ZM_PLUME, K_ZM_EVAP, K_MOMTRAN, K_AERO_SW, K_AERO_LW, K_UPDATE, K_CONVTRAN = range(9)
 KERNEL_NAMES = ["geopotential_t", "zm_trigger", "zm_plume1", "zm_conv_evap", "momtran", "modal_aero_sw", "modal_aero_lw",
-                "physics_update", "convtran", "zm_ascent2", "zm_plume2"]
+                "physics_update", "convtran", "zm_ascent2", "zm_plume2", "modal_aero_sw_diag"]
 
 
 class ZmParams(C.Structure):
@@ -175,6 +175,19 @@ class ModalAeroIO(C.Structure):
         + [(n, PD) for n in ("tauxar", "wa", "ga", "fa")]
         + [("status", PI)]
     )
+
+
+# modal_aero_sw history diagnostics (include/colphys.h COLPHYS_SWD_*): field order of the packed outputs, with the
+# reference's outfld names (modal_aer_opt.F90:1094-1154; the "dn" day+night set)
+SWD_LEV_FIELDS = ("EXTINCTdn", "ABSORBdn", "EXTxASYMdn", "EXTINCTUVdn", "EXTINCTNIRdn")
+SWD_COL_FIELDS = (
+    "AODVISdn", "AODABSdn", "AODTOTdn", "AODVISstdn", "SSAVISdn", "AODxASYMdn", "AODUVdn", "AODNIRdn", "AODUVstdn",
+    "AODNIRstdn", "BURDENSO4dn", "BURDENPOMdn", "BURDENSOAdn", "BURDENBCdn", "BURDENDUSTdn", "BURDENSEASALTdn",
+    "AODABSBCdn", "AODSO4dn", "AODPOMdn", "AODSOAdn", "AODBCdn", "AODDUSTdn", "AODSSdn",
+)
+SWD_NLEV = len(SWD_LEV_FIELDS)
+SWD_NCOL = len(SWD_COL_FIELDS)
+SWD_NMODEF = 3          # per mode: BURDENdn<mm>, AODdn_<mode>, AODdnDUST<mm>
 
 
 def dptr(a: np.ndarray):

@@ -626,6 +626,7 @@ int colphys_aero_tables_set(const colphys_aero_tables *tb)
     };
     AeroDev &A = g_A;
     A.nmodes = tb->nmodes; A.nspec_max = tb->nspec_max; A.nswbands = tb->nswbands; A.nlwbands = tb->nlwbands;
+    A.idx_sw_diag = tb->idx_sw_diag; A.idx_uv_diag = tb->idx_uv_diag; A.idx_nir_diag = tb->idx_nir_diag;
     A.top_lev = tb->top_lev; A.rhoh2o = tb->rhoh2o; A.rga = tb->rga; A.rair = tb->rair; A.xrmin = tb->xrmin; A.xrmax = tb->xrmax;
     const size_t nm = tb->nmodes, ns = tb->nspec_max, nsw = tb->nswbands, nlw = tb->nlwbands;
     const size_t tblsz = (size_t)COLPHYS_PREFI * COLPHYS_PREFR * COLPHYS_NCOEF;
@@ -713,6 +714,23 @@ static int aero_dev(bool sw, int ncol, int pver, const colphys_modal_aero_io *io
 }
 int colphys_modal_aero_sw_dev(int ncol, int pver, const colphys_modal_aero_io *io, void *stream) { return aero_dev(true, ncol, pver, io, stream); }
 int colphys_modal_aero_lw_dev(int ncol, int pver, const colphys_modal_aero_io *io, void *stream) { return aero_dev(false, ncol, pver, io, stream); }
+
+int colphys_modal_aero_sw_diag_dev(int ncol, int pver, const colphys_modal_aero_io *io, double *lev, double *col, void *stream)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    if (!g_aero_set) return fail(COLPHYS_ERR_NOTINIT, "colphys_aero_tables_set has not been called");
+    if (!io || !io->pdeldry || !io->pmid || !io->t || !io->specmmr || !io->dgnumwet || !io->qaerwat || !io->troplevchem ||
+        !io->tauxar || !lev || !col)
+        return fail(COLPHYS_ERR_ARG, "null pointer in colphys_modal_aero_sw_diag_dev (pmid, t, troplevchem and the SW tauxar are required)");
+    const int nsw = g_A.nswbands;
+    if (g_A.idx_sw_diag < 1 || g_A.idx_sw_diag > nsw || g_A.idx_uv_diag < 1 || g_A.idx_uv_diag > nsw || g_A.idx_nir_diag < 1 ||
+        g_A.idx_nir_diag > nsw)
+        return fail(COLPHYS_ERR_ARG, "idx_sw_diag / idx_uv_diag / idx_nir_diag of the aerosol tables must be bands 1..nswbands");
+    ProfScope ps(COLPHYS_K_AERO_SW_DIAG, (hipStream_t)stream);
+    rc = launch_modal_aero_sw_diag(g_A, ncol, pver, *io, lev, col, (hipStream_t)stream);
+    return rc ? fail(rc, "modal_aero_sw_diag launch failed (pver above 256 is not supported)") : COLPHYS_OK;
+}
 
 // =======================================================================================================
 // host-layout (chunk) entry points: Fortran (pcols, nlev, nchunks) <-> device [col][nlev]
@@ -1109,7 +1127,8 @@ int colphys_convtran_chunks(int nchunks, int pcols, int pver, const int32_t *nco
     return s.ok ? COLPHYS_OK : fail(COLPHYS_ERR_HIP, "a staging copy failed");
 }
 
-static int aero_chunks(bool sw, int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io)
+static int aero_chunks(bool sw, int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io,
+                       double *diag_lev = nullptr, double *diag_col = nullptr)
 {
     int rc;
     if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
@@ -1119,7 +1138,11 @@ static int aero_chunks(bool sw, int nchunks, int pcols, int pver, const int32_t 
     const size_t ncd = (size_t)nchunks * pcols, pverp = pver + 1;
     const int nm = g_A.nmodes, ns = g_A.nspec_max, nb = sw ? g_A.nswbands : g_A.nlwbands;
     const size_t nout = sw ? 4 * (size_t)nb * pverp : (size_t)nb * pver;
-    const size_t bytes = 8 * ncd * ((3 + (size_t)nm * (ns + 2)) * pver + 2 * nout + 8) + 256 * 256;
+    const bool diag = diag_lev || diag_col;
+    if (diag && (!sw || !diag_lev || !diag_col || !io->pmid || !io->t || !io->troplevchem))
+        return fail(COLPHYS_ERR_ARG, "SW diagnostics need lev, col, pmid, t and troplevchem");
+    const int ncolf = COLPHYS_SWD_NCOL + COLPHYS_SWD_NMODEF * nm;
+    const size_t bytes = 8 * ncd * ((3 + (size_t)nm * (ns + 2)) * pver + 2 * nout + 8 + (diag ? 2 * ((size_t)COLPHYS_SWD_NLEV * pver + ncolf) : 0)) + 256 * 256;
     if ((rc = stage_reserve(bytes, bytes))) return rc;
     Stager s(nchunks, pcols, ncol, g_pin_arena.p, g_dev_arena.p);
     colphys_modal_aero_io d = *io;
@@ -1130,7 +1153,7 @@ static int aero_chunks(bool sw, int nchunks, int pcols, int pver, const int32_t 
     d.specmmr = s.in_multi(io->specmmr, pver, nm * ns);
     d.dgnumwet = s.in_multi(io->dgnumwet, pver, nm);
     d.qaerwat = s.in_multi(io->qaerwat, pver, nm);
-    d.troplevchem = nullptr;
+    d.troplevchem = diag ? s.in_i(io->troplevchem, 1) : nullptr;
     d.status = s.out<int32_t>(1);
     const int nlevout = sw ? (int)pverp : pver;
     double *o[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1138,6 +1161,12 @@ static int aero_chunks(bool sw, int nchunks, int pcols, int pver, const int32_t 
     d.tauxar = o[0]; d.wa = o[1]; d.ga = o[2]; d.fa = o[3];
     rc = sw ? colphys_modal_aero_sw_dev((int)ncd, pver, &d, nullptr) : colphys_modal_aero_lw_dev((int)ncd, pver, &d, nullptr);
     if (rc) return rc;
+    double *dlev = nullptr, *dcol = nullptr;
+    if (diag) {
+        dlev = s.dc.take<double>((size_t)COLPHYS_SWD_NLEV * ncd * pver);
+        dcol = s.dc.take<double>((size_t)ncolf * ncd);
+        if ((rc = colphys_modal_aero_sw_diag_dev((int)ncd, pver, &d, dlev, dcol, nullptr))) return rc;
+    }
     // device [col][band][lev] -> Fortran (pcols, lev, nbands) per chunk
     double *hdst[4] = {io->tauxar, io->wa, io->ga, io->fa};
     std::vector<double> h(ncd * nb * nlevout);
@@ -1150,9 +1179,20 @@ static int aero_chunks(bool sw, int nchunks, int pcols, int pver, const int32_t 
                         hdst[f][(size_t)c * pcols * nlevout * nb + ((size_t)b * nlevout + k) * pcols + i] =
                             h[(((size_t)c * pcols + i) * nb + b) * nlevout + k];
     }
+    if (diag) {     // device [field][col][lev] -> (pcols, lev, nchunks, field); [field][col] -> (pcols, nchunks, field)
+        for (int f = 0; f < COLPHYS_SWD_NLEV; ++f)
+            s.back(diag_lev + (size_t)f * ncd * pver, (const double *)(dlev + (size_t)f * ncd * pver), pver, false, nullptr);
+        for (int f = 0; f < ncolf; ++f) s.back(diag_col + (size_t)f * ncd, (const double *)(dcol + (size_t)f * ncd), 1, false, nullptr);
+    }
     s.back(io->status, (const int32_t *)d.status, 1, false, nullptr);
     s.drain();
     return s.ok ? COLPHYS_OK : fail(COLPHYS_ERR_HIP, "a staging copy failed");
+}
+int colphys_modal_aero_sw_diag_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io,
+                                      double *lev, double *col)
+{
+    if (!lev || !col) return fail(COLPHYS_ERR_ARG, "null diagnostics output");
+    return aero_chunks(true, nchunks, pcols, pver, ncol, io, lev, col);
 }
 int colphys_modal_aero_sw_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io) { return aero_chunks(true, nchunks, pcols, pver, ncol, io); }
 int colphys_modal_aero_lw_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io) { return aero_chunks(false, nchunks, pcols, pver, ncol, io); }

@@ -53,6 +53,7 @@ struct AeroDev {
     const double *rspecdens;        // [nmodes][nspec_max] 1/specdens
     double rxrange;                 // 1/(xrmax - xrmin)
     int nspec_total;                // sum of nspec over the modes (host mirror)
+    int idx_sw_diag, idx_uv_diag, idx_nir_diag;   // radconstants' diagnostic bands, 1-based (SW history diagnostics)
 };
 constexpr int AERO_NCP = 6;
 constexpr int AERO_TBLP = COLPHYS_PREFI * COLPHYS_PREFR * AERO_NCP;
@@ -301,6 +302,8 @@ int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, con
                    const double *winds_v = nullptr);
 int launch_modal_aero_sw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);
 int launch_modal_aero_lw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);
+int launch_modal_aero_sw_diag(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, double *lev, double *col,
+                              hipStream_t st);
 int launch_physics_update(int ncol, int pver, double dt, double cpair, double qmin, const double *t_in,
                           const double *s_tend, double *t_out, const double *q_in, const double *q_tend, double *q_out,
                           const double *u_in, const double *u_tend, double *u_out, const double *v_in,

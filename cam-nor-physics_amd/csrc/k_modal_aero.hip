@@ -2,7 +2,8 @@
 //
 // Replaces the compute part of /root/reference/physics/modal_aer_opt.F90:
 //   modal_aero_sw :485-1212, modal_aero_lw :1216-1469, modal_size_parameters :1538-1574.
-// (addfld/outfld history diagnostics stay on the host side; DESIGN.md "out of scope".)
+// The values of modal_aero_sw's history diagnostics are computed by modal_aero_sw_diag_kernel below; addfld / outfld and
+// the night-column fill stay in the Fortran shim.
 //
 // Every (column, level) cell is independent and modes only accumulate, so in both kernels here
 //   work item  = one cell; a block is 4 waves = 256 consecutive cells of the [ncol][pver] layout
@@ -442,6 +443,228 @@ __global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(Ae
     if (live && bad && active) atomicOr(io.status + col, COLPHYS_STATUS_DOPAER_RANGE);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// History diagnostics of modal_aero_sw (modal_aer_opt.F90:647-678, 770-831, 896-993, 1046-1154; include/colphys.h
+// colphys_modal_aero_sw_diag_dev).  A second, small kernel behind the radiative one -- a fourteenth of its table work:
+//   * the visible band (idx_sw_diag) is evaluated again per mode, because the species partition (:936-990) and the
+//     absorption / asymmetry sums need the per-mode pabs, pasm, palb that the radiative sums tau, tau*w, tau*w*g fold;
+//   * AODTOT and the UV / near-IR fields are sums over modes of dopaer, i.e. the radiative kernel's tauxar: read back
+//     from it (sum over modes first, then over bands / levels: a reassociation of the reference's mode-outer sums of
+//     positive terms, at rounding level);
+//   * a block owns whole columns (NT / pver of them; thread = (column, level)), so the column sums are ordered sums
+//     over the levels of per-cell terms staged through LDS, eight fields per round, one summing thread per
+//     (column, field); the per-cell terms add the modes in the reference's order.
+// One slice (mode, visible band) in LDS at a time, copied by the LDS-DMA path like in the radiative kernels.
+// ------------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) int *ciptr_t;
+__device__ __forceinline__ ciptr_t as_const(const int *p) { return (ciptr_t)(const void *)p; }
+constexpr int DIAG_ROUND = 8;               // column fields reduced per LDS round
+constexpr int NTYPE = 6;                    // sulfate, p-organic, s-organic, black-c, dust, seasalt (include/colphys.h)
+
+// ordered sum over the levels of field slot j of column cl, by one thread
+__device__ __forceinline__ double level_sum(const double *s_red, int j, int cl, int pver)
+{
+    const double *p = s_red + j * NT + cl * pver;
+    double a = 0.0;
+    for (int k = 0; k < pver; ++k) a = a + p[k];
+    return a;
+}
+
+__global__ __launch_bounds__(NT, 2) void modal_aero_sw_diag_kernel(AeroDev A, int ncol, int pver, int cpb, colphys_modal_aero_io io,
+                                                                 double *__restrict__ lev, double *__restrict__ colf)
+{
+    constexpr int NTAB = 3;
+    constexpr int SLICE = aero_slice_doubles(NTAB);
+    extern __shared__ double smem[];
+    double *s_tbl = smem;                              // the (mode, visible band) slice
+    double *s_red = smem + SLICE;                      // [DIAG_ROUND][NT] per-cell terms of the fields being summed
+
+    const int nb = A.nswbands, ivis = A.idx_sw_diag - 1;
+    const size_t L = (size_t)pver, F = (size_t)ncol * L, LP = L + 1;
+    const int tid = threadIdx.x;
+    const int cl = tid / pver;                         // column of the block
+    const int k = tid - cl * pver + 1;                 // 1-based level
+    const int col = blockIdx.x * cpb + cl;
+    const bool live = cl < cpb && col < ncol;
+    const size_t cc = live ? (size_t)col * L + (k - 1) : F - 1;       // idle lanes shadow the last cell (never stored)
+    const bool active = live && k >= A.top_lev;
+    const double rh2odens = 1.0 / A.rhoh2o;
+    const double *slices = A.slices_sw;
+
+    const double pdel = io.pdeldry[cc];
+    const double mass = pdel * A.rga;                                   // :644
+    const double air_density = io.pmid[cc] / (A.rair * io.t[cc]);       // :645
+    const bool strat = live && k <= io.troplevchem[live ? col : 0];     // :903, 913, 932
+
+    // column totals over all bands / in the UV and near-IR bands from the radiative kernel's tauxar
+    double t_tot = 0.0, t_uv = 0.0, t_nir = 0.0;
+    if (active) {
+        const double *tau = io.tauxar + (size_t)col * nb * LP + k;
+        for (int ib = 0; ib < nb; ++ib) t_tot = t_tot + tau[(size_t)ib * LP];
+        t_uv = tau[(size_t)(A.idx_uv_diag - 1) * LP];
+        t_nir = tau[(size_t)(A.idx_nir_diag - 1) * LP];
+    }
+
+    // per-cell sums over the modes (reference order of the modes)
+    double extinct = 0.0, absorb = 0.0, asymext = 0.0;
+    double c_aodvis = 0.0, c_aodabs = 0.0, c_ssavis = 0.0, c_asymvis = 0.0, c_aodabsbc = 0.0;
+    double c_burden[NTYPE], c_aod[NTYPE];
+#pragma unroll
+    for (int ty = 0; ty < NTYPE; ++ty) { c_burden[ty] = 0.0; c_aod[ty] = 0.0; }
+
+    const int nred = min(cpb, ncol - (int)blockIdx.x * cpb);            // columns of this block that exist
+
+    for (int m = 0; m < A.nmodes; ++m) {                                // :706
+        const int nspec = A.nspec[m];
+        slice_issue<SLICE>(slices + ((size_t)m * nb + ivis) * SLICE, s_tbl);
+        const double *s_refr = s_tbl + NTAB * TBLP, *s_refi = s_refr + NR;
+        const double *s_rdxr = s_refi + NI, *s_rdxi = s_rdxr + NR;
+
+        double v[NSMAX], radsurf, logradsurf, cheb[NC];
+        const double dgn = io.dgnumwet[m * F + cc];
+        const double qw = io.qaerwat[m * F + cc];
+#pragma unroll
+        for (int l = 0; l < NSMAX; ++l) {
+            v[l] = 0.0;
+            if (l < nspec) v[l] = io.specmmr[((size_t)m * A.nspec_max + l) * F + cc];
+        }
+        size_parameters(A, as_const(A.explnsigma)[m], dgn, radsurf, logradsurf, cheb);
+
+        // species loop :758-832 at the visible band
+        cptr_t ri = as_const(A.specrefindex_sw + ((size_t)m * A.nspec_max * nb + ivis) * 2);
+        double cre = 0.0, cim = 0.0, dryvol = 0.0, dustvol = 0.0, burden = 0.0;
+        double scat[NTYPE], absb[NTYPE], hyg[NTYPE];
+#pragma unroll
+        for (int ty = 0; ty < NTYPE; ++ty) { scat[ty] = 0.0; absb[ty] = 0.0; hyg[ty] = 0.0; }
+#pragma unroll
+        for (int l = 0; l < NSMAX; ++l) {
+            if (l < nspec) {
+                const double vol = v[l] * as_const(A.rspecdens)[m * A.nspec_max + l];   // :765 as a product, like the radiative kernel
+                const double re = ri[(size_t)l * nb * 2], im = ri[(size_t)l * nb * 2 + 1];
+                dryvol = dryvol + vol;
+                cre = cre + vol * re;
+                cim = cim + vol * im;
+                const double bm = v[l] * mass;                          // :777
+                burden = burden + bm;
+                const int sty = as_const(A.spectype)[m * A.nspec_max + l];
+                const double hy = as_const(A.hygro)[m * A.nspec_max + l];
+#pragma unroll
+                for (int ty = 0; ty < NTYPE; ++ty) {                    // :780-829; sty is wave-uniform
+                    const bool is = (sty == ty);
+                    c_burden[ty] = c_burden[ty] + (is && active ? bm : 0.0);
+                    scat[ty] = is ? vol * re : scat[ty];                // assignments: the last species of a type stays
+                    absb[ty] = is ? -(vol * im) : absb[ty];
+                    hyg[ty] = is ? vol * hy : hyg[ty];
+                }
+                dustvol = (sty == 4) ? vol : dustvol;
+            }
+        }
+        double watervol = qw * rh2odens;                                // :835-844
+        double wetvol = watervol + dryvol;
+        if (watervol < 0.0) { watervol = 0.0; wetvol = dryvol; }
+        const bool small = logradsurf <= A.xrmax;
+        const double wetinv = 1.0 / fmax(wetvol, 1.e-60);
+        cptr_t crefw = as_const(A.crefwsw + ivis * 2);
+        const double cwr = crefw[0], cwi = crefw[1];
+        cre = (cre + watervol * cwr) * wetinv;                          // :846-850
+        cim = (cim + watervol * cwi) * wetinv;
+        const double refr = cre, refi = fabs(cim);
+
+        __syncthreads();                                                // the slice has landed
+        cptr_t g_grid = as_const(slices + ((size_t)m * nb + ivis) * SLICE + NTAB * TBLP);
+        const Wght wr = calcwghts<NR>(g_grid, s_refr, s_rdxr, refr);    // :857-862
+        const Wght wi = calcwghts<NI>(g_grid + NR, s_refi, s_rdxi, refi);
+        double pext = interp_cheb(s_tbl, wr, wi, cheb);
+        double pabs = interp_cheb(s_tbl + TBLP, wr, wi, cheb);
+        const double pasm = interp_cheb(s_tbl + 2 * TBLP, wr, wi, cheb);
+        const double pe = exp(pext);                                    // :869-877
+        pext = small ? pe : 1.5 / (radsurf * A.rhoh2o);
+        pext = pext * wetvol * A.rhoh2o;                                // :881-894
+        pabs = pabs * wetvol * A.rhoh2o;
+        pabs = fmax(0.0, pabs);
+        pabs = fmin(pext, pabs);
+        const double palb = 1.0 - pabs / fmax(pext, 1.e-40);
+        const double dopaer = pext * mass;
+
+        // :921-934
+        extinct = extinct + dopaer * air_density / mass;
+        absorb = absorb + pabs * air_density;
+        asymext = asymext + dopaer * pasm * air_density / mass;
+        double dustaod_m = 0.0;
+        if (active) {
+            c_aodvis = c_aodvis + dopaer;
+            c_aodabs = c_aodabs + pabs * mass;
+            c_ssavis = c_ssavis + dopaer * palb;
+            c_asymvis = c_asymvis + dopaer * pasm;
+            if (wetvol > 1.e-40) {                                      // :936-990
+                dustaod_m = dopaer * dustvol / wetvol;
+                const double scath2o = watervol * cwr, absh2o = -(watervol * cwi);
+                const double sumscat = scat[0] + scat[1] + scat[2] + scat[3] + scat[4] + scat[5] + scath2o;
+                const double sumabs = absb[0] + absb[1] + absb[2] + absb[3] + absb[4] + absb[5] + absh2o;
+                const double sumhygro = hyg[0] + hyg[1] + hyg[2] + hyg[3] + hyg[4] + hyg[5];
+#pragma unroll
+                for (int ty = 0; ty < NTYPE; ++ty) {
+                    const double sc = (scat[ty] + scath2o * hyg[ty] / sumhygro) / sumscat;
+                    const double ab = (absb[ty] + absh2o * hyg[ty] / sumhygro) / sumabs;
+                    if (ty == 3) c_aodabsbc = c_aodabsbc + ab * dopaer * (1.0 - palb);      // :970
+                    c_aod[ty] = c_aod[ty] + (ab * (1.0 - palb) + palb * sc) * dopaer;       // :972-988
+                }
+            }
+        }
+        // the three per-mode column fields :1050-1057
+        s_red[0 * NT + tid] = active ? burden : 0.0;
+        s_red[1 * NT + tid] = active ? dopaer : 0.0;
+        s_red[2 * NT + tid] = dustaod_m;
+        __syncthreads();                                                // also: every thread is done with the slice
+        if (tid < nred * COLPHYS_SWD_NMODEF) {
+            const int rc = tid / COLPHYS_SWD_NMODEF, j = tid - rc * COLPHYS_SWD_NMODEF;
+            colf[(size_t)(COLPHYS_SWD_NCOL + COLPHYS_SWD_NMODEF * m + j) * ncol + (size_t)blockIdx.x * cpb + rc] = level_sum(s_red, j, rc, pver);
+        }
+        __syncthreads();
+    }
+
+    if (live) {
+        const size_t o = (size_t)col * L + (k - 1);
+        lev[(size_t)COLPHYS_SWD_LEV_EXTINCT * F + o] = active ? extinct : 0.0;
+        lev[(size_t)COLPHYS_SWD_LEV_ABSORB * F + o] = active ? absorb : 0.0;
+        lev[(size_t)COLPHYS_SWD_LEV_ASYMEXT * F + o] = active ? asymext : 0.0;
+        lev[(size_t)COLPHYS_SWD_LEV_EXTINCTUV * F + o] = active ? t_uv * air_density / mass : 0.0;
+        lev[(size_t)COLPHYS_SWD_LEV_EXTINCTNIR * F + o] = active ? t_nir * air_density / mass : 0.0;
+    }
+
+    // the 23 column fields in three rounds of eight
+    double term[3 * DIAG_ROUND];
+#pragma unroll
+    for (int j = 0; j < 3 * DIAG_ROUND; ++j) term[j] = 0.0;
+    term[COLPHYS_SWD_COL_AODVIS] = c_aodvis;
+    term[COLPHYS_SWD_COL_AODABS] = c_aodabs;
+    term[COLPHYS_SWD_COL_AODTOT] = t_tot;
+    term[COLPHYS_SWD_COL_AODVISST] = strat ? c_aodvis : 0.0;
+    term[COLPHYS_SWD_COL_SSAVIS] = c_ssavis;
+    term[COLPHYS_SWD_COL_ASYMVIS] = c_asymvis;
+    term[COLPHYS_SWD_COL_AODUV] = t_uv;
+    term[COLPHYS_SWD_COL_AODNIR] = t_nir;
+    term[COLPHYS_SWD_COL_AODUVST] = strat ? t_uv : 0.0;
+    term[COLPHYS_SWD_COL_AODNIRST] = strat ? t_nir : 0.0;
+#pragma unroll
+    for (int ty = 0; ty < NTYPE; ++ty) {
+        term[COLPHYS_SWD_COL_BURDEN0 + ty] = c_burden[ty];
+        term[COLPHYS_SWD_COL_AOD0 + ty] = c_aod[ty];
+    }
+    term[COLPHYS_SWD_COL_AODABSBC] = c_aodabsbc;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int j = 0; j < DIAG_ROUND; ++j) s_red[j * NT + tid] = term[r * DIAG_ROUND + j];
+        __syncthreads();
+        if (tid < nred * DIAG_ROUND) {
+            const int rc = tid / DIAG_ROUND, j = tid - rc * DIAG_ROUND, f = r * DIAG_ROUND + j;
+            if (f < COLPHYS_SWD_NCOL) colf[(size_t)f * ncol + (size_t)blockIdx.x * cpb + rc] = level_sum(s_red, j, rc, pver);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 static int launch_aero(bool sw, const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st)
@@ -494,4 +717,15 @@ int launch_modal_aero_sw(const AeroDev &A, int ncol, int pver, const colphys_mod
 int launch_modal_aero_lw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st)
 {
     return launch_aero(false, A, ncol, pver, io, st);
+}
+
+int launch_modal_aero_sw_diag(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, double *lev, double *col,
+                              hipStream_t st)
+{
+    if (A.nspec_max > NSMAX || pver > NT) return COLPHYS_ERR_UNSUPPORTED;
+    const int cpb = NT / pver;
+    const size_t lds = ((size_t)aero_slice_doubles(3) + (size_t)DIAG_ROUND * NT) * sizeof(double);
+    const dim3 grid((unsigned)((ncol + cpb - 1) / cpb));
+    hipLaunchKernelGGL(modal_aero_sw_diag_kernel, grid, dim3(NT), lds, st, A, ncol, pver, cpb, io, lev, col);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }

@@ -69,6 +69,7 @@ EXPORTED_SYMBOLS = [
     "colphys_aero_tables_set",
     "colphys_modal_aero_sw_dev", "colphys_modal_aero_lw_dev",
     "colphys_modal_aero_sw_chunks", "colphys_modal_aero_lw_chunks",
+    "colphys_modal_aero_sw_diag_dev", "colphys_modal_aero_sw_diag_chunks",
     "colphys_profile_enable", "colphys_profile_reset", "colphys_profile_get", "colphys_math_probe_dev",
 ]
 
@@ -347,6 +348,20 @@ class ColumnPhysics:
             setattr(io, k, _p(out[k]))
         io.status = _p(out["status"], abi.PI)
         self._check(self.lib.colphys_modal_aero_sw_dev(C.c_int(n), C.c_int(pver), C.byref(io), self._stream()))
+        return out
+
+    def modal_aero_sw_diag(self, pdeldry, pmid, t, specmmr, dgnumwet, qaerwat, troplevchem, tauxar, out=None):
+        """modal_aero_sw's history diagnostics (modal_aer_opt.F90:896-993, 1046-1154), after modal_aero_sw has filled
+        `tauxar`.  Returns lev [SWD_NLEV][n][pver] and col [SWD_NCOL + 3*nmodes][n] in the field order of
+        abi.SWD_LEV_FIELDS / abi.SWD_COL_FIELDS (+ burden, aodmode, dustaodmode per mode)."""
+        n, pver = pdeldry.shape
+        if out is None:
+            out = dict(lev=self.empty(abi.SWD_NLEV, n, pver), col=self.empty(abi.SWD_NCOL + abi.SWD_NMODEF * self.tables.nmodes, n))
+        io = self._aero_io(pdeldry, specmmr, dgnumwet, qaerwat, self._f64(pmid), self._f64(t))
+        io.troplevchem = _p(troplevchem, abi.PI)
+        io.tauxar = _p(self._f64(tauxar))
+        self._check(self.lib.colphys_modal_aero_sw_diag_dev(C.c_int(n), C.c_int(pver), C.byref(io), _p(out["lev"]), _p(out["col"]),
+                                                            self._stream()))
         return out
 
     def modal_aero_lw(self, pdeldry, specmmr, dgnumwet, qaerwat, out=None):

@@ -86,6 +86,14 @@ module colphys_c_api
       integer(c_int32_t), intent(in) :: ncol(*)
       type(colphys_modal_aero_io), intent(in) :: io
     end function
+    integer(c_int) function colphys_modal_aero_sw_diag_chunks(nchunks, pcols, pver, ncol, io, lev, col) &
+         bind(C, name='colphys_modal_aero_sw_diag_chunks')
+      import
+      integer(c_int), value :: nchunks, pcols, pver
+      integer(c_int32_t), intent(in) :: ncol(*)
+      type(colphys_modal_aero_io), intent(in) :: io
+      type(c_ptr), value :: lev, col
+    end function
     integer(c_int) function colphys_modal_aero_lw_chunks(nchunks, pcols, pver, ncol, io) &
          bind(C, name='colphys_modal_aero_lw_chunks')
       import

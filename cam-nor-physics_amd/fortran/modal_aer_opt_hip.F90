@@ -13,8 +13,11 @@
 ! 679-681, 717-724, 759-762, 1334-1355, 1485-1530.  The shim hands the tables to the engine once
 ! (colphys_aero_tables_set) and per call marshals the chunk's fields to colphys_modal_aero_{sw,lw}_chunks.
 !
-! Not offloaded (DESIGN.md "out of scope"): the ~40 history diagnostics of modal_aero_sw (addfld/outfld :173-480,
-! :899-993, 1045-1208) and the diagnostic radiation lists (list_idx > 0, :683-699), which need the absent
+! History diagnostics of modal_aero_sw (:896-993, 1046-1209): the values come from the engine
+! (colphys_modal_aero_sw_diag_chunks, one upload shared with the radiative kernel); the night-column fill and the
+! outfld calls -- same names, same order, "dn" field before its day-only twin -- are here.  addfld registration
+! (:173-480) is the host model's history setup and is not repeated.
+! Not offloaded (DESIGN.md "out of scope"): the diagnostic radiation lists (list_idx > 0, :683-699), which need the absent
 ! modal_aero_calcsize / modal_aero_wateruptake; the shim aborts on list_idx > 0 instead of returning wrong numbers.
 !
 ! Module name: `modal_aer_opt_hip` by default; with -DCOLPHYS_DROPIN_NAMES it is `modal_aer_opt`, a whole-module
@@ -44,6 +47,8 @@ module AER_MODULE
   use cam_pio_utils,     only: cam_pio_openfile
   use cam_logfile,       only: iulog
   use cam_abortutils,    only: endrun
+  use cam_history,       only: outfld
+  use cam_history_support, only: fillvalue
   use colphys_c_api
   implicit none
   private
@@ -298,7 +303,8 @@ contains
 
   !---------------------------------------------------------------------------------------------------------
   subroutine modal_aero_sw(list_idx, state, pbuf, nnite, idxnite, tauxar, wa, ga, fa)
-    ! modal_aer_opt.F90:485-1212 (radiative properties; the night-column list only masks history fields there)
+    ! modal_aer_opt.F90:485-1212
+    use tropopause, only: tropopause_findChemTrop
     integer,             intent(in) :: list_idx
     type(physics_state), intent(in), target :: state
     type(physics_buffer_desc), pointer :: pbuf(:)
@@ -309,25 +315,94 @@ contains
     real(r8), intent(out), target :: ga(pcols,0:pver,nswbands)
     real(r8), intent(out), target :: fa(pcols,0:pver,nswbands)
 
+    ! field order of the engine's packed diagnostics (include/colphys.h COLPHYS_SWD_*)
+    integer, parameter :: nlevf = 5, ncolf0 = 23
+    character(len=16), parameter :: lev_names(nlevf) = (/ 'EXTINCT   ', 'ABSORB    ', 'EXTxASYM  ', 'EXTINCTUV ', 'EXTINCTNIR' /)
+    character(len=16), parameter :: col_names(ncolf0) = (/ &
+         'AODVIS       ', 'AODABS       ', 'AODTOT       ', 'AODVISst     ', 'SSAVIS       ', 'AODxASYM     ', 'AODUV        ', &
+         'AODNIR       ', 'AODUVst      ', 'AODNIRst     ', 'BURDENSO4    ', 'BURDENPOM    ', 'BURDENSOA    ', 'BURDENBC     ', &
+         'BURDENDUST   ', 'BURDENSEASALT', 'AODABSBC     ', 'AODSO4       ', 'AODPOM       ', 'AODSOA       ', 'AODBC        ', &
+         'AODDUST      ', 'AODSS        ' /)
+    ! outfld order of the reference: the seven summed visible-band fields (:1094-1118), then the climate-list set (:1130-1209)
+    integer, parameter :: first_set(7)  = (/ 101, 102, 1, 2, 3, 4, 103 /)            ! 100 + level field, else column field
+    integer, parameter :: second_set(23) = (/ 5, 6, 104, 105, 7, 8, 9, 10, 15, 11, 12, 13, 14, 16, 17, 22, 18, 19, 20, 21, 23, 0, 0 /)
+
     real(c_double), allocatable, target :: pdeldry(:,:), specmmr(:,:,:,:), dgnumwet(:,:,:), qaerwat(:,:,:)
-    integer(c_int32_t), target :: status(pcols)
+    real(c_double), allocatable, target :: pmid(:,:), t(:,:), dlev(:,:,:), dcol(:,:)
+    integer(c_int32_t), target :: status(pcols), troplevchem(pcols)
     integer(c_int32_t) :: ncol_c(1)
     type(colphys_modal_aero_io) :: io
-    integer :: rc
+    integer :: rc, ncol, lchnk, m, i, j, f
+    character(len=32) :: outname, modename
 
+    ncol = state%ncol; lchnk = state%lchnk
     allocate(pdeldry(pcols,pver), specmmr(pcols,pver,max(nspec_max,1),max(nmodes_clim,1)), &
-             dgnumwet(pcols,pver,max(nmodes_clim,1)), qaerwat(pcols,pver,max(nmodes_clim,1)))
+             dgnumwet(pcols,pver,max(nmodes_clim,1)), qaerwat(pcols,pver,max(nmodes_clim,1)), &
+             pmid(pcols,pver), t(pcols,pver), dlev(pcols,pver,nlevf), dcol(pcols,ncolf0+3*max(nmodes_clim,1)))
     call marshal_inputs('modal_aero_sw', list_idx, state, pbuf, pdeldry, specmmr, dgnumwet, qaerwat)
+    pmid = 1._r8; t = 1._r8; troplevchem = 1
+    pmid(:ncol,:) = state%pmid(:ncol,:); t(:ncol,:) = state%t(:ncol,:)
+    call tropopause_findChemTrop(state, troplevchem)                                ! :679
     status = 0
-    io%pdeldry = c_loc(pdeldry); io%pmid = c_null_ptr; io%t = c_null_ptr
+    io%pdeldry = c_loc(pdeldry); io%pmid = c_loc(pmid); io%t = c_loc(t)
     io%specmmr = c_loc(specmmr); io%dgnumwet = c_loc(dgnumwet); io%qaerwat = c_loc(qaerwat)
-    io%troplevchem = c_null_ptr
+    io%troplevchem = c_loc(troplevchem)
     io%tauxar = c_loc(tauxar); io%wa = c_loc(wa); io%ga = c_loc(ga); io%fa = c_loc(fa)
     io%status = c_loc(status)
-    ncol_c(1) = state%ncol
-    rc = colphys_modal_aero_sw_chunks(1, pcols, pver, ncol_c, io)
+    ncol_c(1) = ncol
+    rc = colphys_modal_aero_sw_diag_chunks(1, pcols, pver, ncol_c, io, c_loc(dlev), c_loc(dcol))
     if (rc /= COLPHYS_OK) call endrun('modal_aero_sw (colphys): '//trim(colphys_error_message()))
-    call check_status('modal_aero_sw', state%lchnk, state%ncol, status, 'exit from modal_aero_sw')
+    call check_status('modal_aero_sw', lchnk, ncol, status, 'exit from modal_aero_sw')
+
+    ! ---- history output, as the reference orders it ---------------------------------------------------------
+    do m = 1, nmodes_clim                                                           ! :1046-1074
+      call rad_cnst_get_info(0, m, mode_type=modename)
+      j = ncolf0 + 3*(m-1)
+      write(outname,'(a,i2.2)') 'BURDENdn', m;  call outfld(trim(outname), dcol(:,j+1), pcols, lchnk)
+      outname = 'AODdn_'//trim(modename);       call outfld(trim(outname), dcol(:,j+2), pcols, lchnk)
+      write(outname,'(a,i2.2)') 'AODdnDUST', m; call outfld(trim(outname), dcol(:,j+3), pcols, lchnk)
+      do i = 1, nnite
+        dcol(idxnite(i), j+1:j+3) = fillvalue
+      end do
+      write(outname,'(a,i2.2)') 'BURDEN', m;    call outfld(trim(outname), dcol(:,j+1), pcols, lchnk)
+      outname = 'AOD_'//trim(modename);         call outfld(trim(outname), dcol(:,j+2), pcols, lchnk)
+      write(outname,'(a,i2.2)') 'AODDUST', m;   call outfld(trim(outname), dcol(:,j+3), pcols, lchnk)
+    end do
+
+    call put_set(first_set, 7, 'dn')                                                ! :1094-1100
+    do i = 1, nnite                                                                 ! :1102-1110
+      dlev(idxnite(i),:,1:3) = fillvalue
+      dcol(idxnite(i),1:4)   = fillvalue
+    end do
+    call put_set(first_set, 7, '')                                                  ! :1112-1118
+
+    do i = 1, ncol                                                                  ! :1122-1128: aodvis is night-filled by now
+      if (dcol(i,1) > 1.e-10_r8) then
+        dcol(i,5) = dcol(i,5)/dcol(i,1)
+      else
+        dcol(i,5) = 0.925_r8
+      end if
+    end do
+    call put_set(second_set, 21, 'dn')                                              ! :1130-1154
+    do i = 1, nnite                                                                 ! :1157-1183
+      dlev(idxnite(i),:,4:5) = fillvalue
+      dcol(idxnite(i),5:ncolf0) = fillvalue
+    end do
+    call put_set(second_set, 21, '')                                                ! :1185-1209
+
+  contains
+    subroutine put_set(set, n, suffix)
+      integer, intent(in) :: set(:), n
+      character(len=*), intent(in) :: suffix
+      integer :: q
+      do q = 1, n
+        if (set(q) > 100) then
+          call outfld(trim(lev_names(set(q)-100))//suffix, dlev(:,:,set(q)-100), pcols, lchnk)
+        else
+          call outfld(trim(col_names(set(q)))//suffix, dcol(:,set(q)), pcols, lchnk)
+        end if
+      end do
+    end subroutine put_set
   end subroutine modal_aero_sw
 
   !---------------------------------------------------------------------------------------------------------

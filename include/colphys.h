@@ -24,6 +24,7 @@
  *                                    refractive indices crefwsw/crefwlw :59-60,1525-1530
  *   colphys_modal_aero_sw*           modal_aero_sw            physics/modal_aer_opt.F90:485-1212
  *   colphys_modal_aero_lw*           modal_aero_lw            physics/modal_aer_opt.F90:1216-1469
+ *   colphys_modal_aero_sw_diag*      modal_aero_sw's history diagnostics   physics/modal_aer_opt.F90:647-678, 770-831, 896-993, 1046-1154
  *
  * Two families of entry points:
  *
@@ -372,6 +373,51 @@ int colphys_modal_aero_sw_chunks(int nchunks, int pcols, int pver, const int32_t
 int colphys_modal_aero_lw_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io);
 
 /* ---------------------------------------------------------------------------------------------------
+ * modal_aero_sw history diagnostics  (modal_aer_opt.F90:647-678 initialisation, :770-831, :896-993 accumulation,
+ * :1046-1154 the values handed to outfld; climate list, list_idx = 0)
+ *
+ * A second output set of modal_aero_sw, computed from the same inputs AFTER colphys_modal_aero_sw_dev has filled
+ * io->tauxar (the all-band / UV / near-IR totals are read from it: tauxar(:,k,isw) is the sum over modes of dopaer).
+ * io->pmid, io->t and io->troplevchem are required here.  The visible band (idx_sw_diag) is re-evaluated per mode for
+ * the quantities that need the per-mode pabs / pasm / palb and the species partition.
+ *   lev  [COLPHYS_SWD_NLEV][ncol][pver]            level fields (1/m), zero above top_lev
+ *   col  [COLPHYS_SWD_NCOL + 3*nmodes][ncol]       column fields; per mode m (0-based) at COLPHYS_SWD_NCOL + 3*m:
+ *                                                   burden (BURDENdn<mm>), aodmode (AODdn_<mode>), dustaodmode (AODdnDUST<mm>)
+ * These are the reference's "dn" (day+night) values; the night-column fill of the day-only twins (:1059-1063,
+ * :1102-1110, :1157-1183) and the outfld calls stay in the Fortran shim.  SSAVIS is the sum of dopaer*palb (:929): the
+ * reference divides it by aodvis AFTER aodvis' night columns have been overwritten with fillvalue (:1106, :1122-1128),
+ * so that step belongs to the caller that owns the night-column list.
+ * ------------------------------------------------------------------------------------------------- */
+#define COLPHYS_SWD_LEV_EXTINCT     0   /* EXTINCTdn     */
+#define COLPHYS_SWD_LEV_ABSORB      1   /* ABSORBdn      */
+#define COLPHYS_SWD_LEV_ASYMEXT     2   /* EXTxASYMdn    */
+#define COLPHYS_SWD_LEV_EXTINCTUV   3   /* EXTINCTUVdn   */
+#define COLPHYS_SWD_LEV_EXTINCTNIR  4   /* EXTINCTNIRdn  */
+#define COLPHYS_SWD_NLEV            5
+#define COLPHYS_SWD_COL_AODVIS      0   /* AODVISdn      */
+#define COLPHYS_SWD_COL_AODABS      1   /* AODABSdn      */
+#define COLPHYS_SWD_COL_AODTOT      2   /* AODTOTdn      */
+#define COLPHYS_SWD_COL_AODVISST    3   /* AODVISstdn    */
+#define COLPHYS_SWD_COL_SSAVIS      4   /* SSAVISdn before its normalisation */
+#define COLPHYS_SWD_COL_ASYMVIS     5   /* AODxASYMdn    */
+#define COLPHYS_SWD_COL_AODUV       6   /* AODUVdn       */
+#define COLPHYS_SWD_COL_AODNIR      7   /* AODNIRdn      */
+#define COLPHYS_SWD_COL_AODUVST     8   /* AODUVstdn     */
+#define COLPHYS_SWD_COL_AODNIRST    9   /* AODNIRstdn    */
+#define COLPHYS_SWD_COL_BURDEN0     10  /* BURDEN{SO4,POM,SOA,BC,DUST,SEASALT}dn in the spectype order 0..5 */
+#define COLPHYS_SWD_COL_AODABSBC    16  /* AODABSBCdn    */
+#define COLPHYS_SWD_COL_AOD0        17  /* AOD{SO4,POM,SOA,BC,DUST,SS}dn in the spectype order 0..5 */
+#define COLPHYS_SWD_NCOL            23
+#define COLPHYS_SWD_NMODEF          3   /* per-mode column fields */
+
+int colphys_modal_aero_sw_diag_dev(int ncol, int pver, const colphys_modal_aero_io *io, double *lev, double *col, void *stream);
+/* host (chunk) form: runs modal_aero_sw AND its diagnostics on one upload.  io as for colphys_modal_aero_sw_chunks plus
+ * pmid, t (pcols,pver,nchunks) and troplevchem (pcols,nchunks); lev (pcols,pver,nchunks,COLPHYS_SWD_NLEV);
+ * col (pcols,nchunks,COLPHYS_SWD_NCOL + 3*nmodes) */
+int colphys_modal_aero_sw_diag_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io,
+                                      double *lev, double *col);
+
+/* ---------------------------------------------------------------------------------------------------
  * zm_conv_tend on resident data  (zm_conv_intr.F90:441-905, the part between the pbuf lookups and convtran1)
  *
  * The whole deep-convection tendency of a rank in ONE call, state1 never leaving the device:
@@ -430,6 +476,7 @@ int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dy
 #define COLPHYS_K_CONVTRAN     8
 #define COLPHYS_K_ZM_ASCENT2   9   /* second dilute ascent of the triggered columns */
 #define COLPHYS_K_ZM_PLUME2    10  /* second ensemble pass, closure, tendencies, gather */
+#define COLPHYS_K_AERO_SW_DIAG 11  /* modal_aero_sw history diagnostics */
 #define COLPHYS_K_COUNT        12
 int colphys_profile_enable(int on);
 int colphys_profile_reset(void);

@@ -195,6 +195,16 @@ class COracle:
         self.lib.oracle_modal_aero_sw(C.c_int(n), C.c_int(pver), C.byref(io))
         return o
 
+    def modal_aero_sw_diag(self, state, aer):
+        """lev [SWD_NLEV][n][pver], col [SWD_NCOL + 3*nmodes][n] (include/colphys.h)"""
+        n, pver = state["t"].shape
+        keep = []
+        io = self._aero_io(state, aer, keep)
+        lev = np.zeros((abi.SWD_NLEV, n, pver))
+        col = np.zeros((abi.SWD_NCOL + abi.SWD_NMODEF * self.tables.nmodes, n))
+        self.lib.oracle_modal_aero_sw_diag(C.c_int(n), C.c_int(pver), C.byref(io), abi.dptr(lev), abi.dptr(col))
+        return dict(lev=lev, col=col)
+
     def modal_aero_lw(self, state, aer):
         n, pver = state["t"].shape
         nlw = self.tables.nlwbands

@@ -39,6 +39,7 @@ void oracle_convtran(int ncol, int pver, int pcols, int ncnst, double dt, const 
 void oracle_aero_tables_set(const colphys_aero_tables *tb);
 void oracle_modal_aero_sw(int ncol, int pver, const colphys_modal_aero_io *io);
 void oracle_modal_aero_lw(int ncol, int pver, const colphys_modal_aero_io *io);
+void oracle_modal_aero_sw_diag(int ncol, int pver, const colphys_modal_aero_io *io, double *lev, double *col);
 
 /* L0 seams, exported so tests can pin them against the Fortran stubs */
 void   oracle_qsat_water(double t, double p, double *es, double *qs);

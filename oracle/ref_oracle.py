@@ -178,6 +178,19 @@ class RefOracle:
         self.lib.ref_modal_aero_sw(C.c_int(n), *[_d(x) for x in a], _i(tl), *[_d(o[k]) for k in ("tauxar", "wa", "ga", "fa")])
         return o
 
+    def modal_aero_sw_diag(self, state, aer, nite=None):
+        """What modal_aero_sw hands to outfld: lev/col = the "dn" fields, lev_f/col_f = the day-only twins (night columns,
+        nite[i] != 0, carry the reference's fillvalue).  Layouts: include/colphys.h colphys_modal_aero_sw_diag_dev."""
+        n, pver = state["t"].shape
+        nmodes = self.aero_dims[0]
+        a, tl = self._aero_args(state, aer)
+        nt = np.zeros(n, dtype=np.int32) if nite is None else np.ascontiguousarray(nite, dtype=np.int32)
+        ncf = 23 + 3 * nmodes
+        o = dict(lev=np.zeros((5, n, pver)), col=np.zeros((ncf, n)), lev_f=np.zeros((5, n, pver)), col_f=np.zeros((ncf, n)))
+        self.lib.ref_modal_aero_sw_diag(C.c_int(n), *[_d(x) for x in a], _i(tl), _i(nt),
+                                        *[_d(o[k]) for k in ("lev", "col", "lev_f", "col_f")])
+        return o
+
     def modal_aero_lw(self, state, aer):
         n, pver = state["t"].shape
         nlw = self.aero_dims[3]

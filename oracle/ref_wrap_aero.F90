@@ -117,6 +117,78 @@ contains
     end do
   end subroutine ref_modal_aero_sw
 
+  ! modal_aero_sw once more, this time for what it hands to outfld (captured by the cam_history stand-in): the "dn"
+  ! fields in lev/col (layouts of colphys_modal_aero_sw_diag_dev, include/colphys.h) and their day-only twins, in
+  ! which the columns flagged in nite carry fillvalue, in lev_f/col_f.
+  subroutine ref_modal_aero_sw_diag(n, pdeldry, pmid, t, specmmr, dgnumwet, qaerwat, troplev, nite, lev, col, lev_f, col_f) &
+       bind(C, name='ref_modal_aero_sw_diag')
+    use cam_history, only: cap_on, cap_n, outfld_captured
+    integer(c_int), value :: n
+    real(c_double), intent(in)  :: pdeldry(pver,n), pmid(pver,n), t(pver,n)
+    real(c_double), intent(in)  :: specmmr(pver,n,nsmax,nm), dgnumwet(pver,n,nm), qaerwat(pver,n,nm)
+    integer(c_int), intent(in)  :: troplev(n), nite(n)
+    real(c_double), intent(out) :: lev(pver,n,5), col(n,23+3*nm), lev_f(pver,n,5), col_f(n,23+3*nm)
+    character(len=16), parameter :: lev_names(5) = (/ 'EXTINCT   ', 'ABSORB    ', 'EXTxASYM  ', 'EXTINCTUV ', 'EXTINCTNIR' /)
+    character(len=16), parameter :: col_names(23) = (/ &
+         'AODVIS       ', 'AODABS       ', 'AODTOT       ', 'AODVISst     ', 'SSAVIS       ', 'AODxASYM     ', 'AODUV        ', &
+         'AODNIR       ', 'AODUVst      ', 'AODNIRst     ', 'BURDENSO4    ', 'BURDENPOM    ', 'BURDENSOA    ', 'BURDENBC     ', &
+         'BURDENDUST   ', 'BURDENSEASALT', 'AODABSBC     ', 'AODSO4       ', 'AODPOM       ', 'AODSOA       ', 'AODBC        ', &
+         'AODDUST      ', 'AODSS        ' /)
+    type(physics_state) :: state
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    real(r8) :: tau_c(pcols,0:pver,nswbands), wa_c(pcols,0:pver,nswbands), ga_c(pcols,0:pver,nswbands), fa_c(pcols,0:pver,nswbands)
+    real(r8) :: buf(pcols,pverp)
+    integer :: idxnite(pcols), nnite, c0, nc, ic, i, k, f, m, nl
+    character(len=32) :: nm_dn, nm_day
+    nullify(pbuf)
+    allocate(state%t(pcols,pver), state%pmid(pcols,pver), state%pdeldry(pcols,pver))
+    c0 = 0; ic = 0
+    do while (c0 < n)
+      nc = min(pcols, n - c0); ic = ic + 1
+      state%lchnk = ic
+      call load_chunk(n, c0, nc, pdeldry, pmid, t, specmmr, dgnumwet, qaerwat, troplev, state)
+      nnite = 0
+      do i = 1, nc
+        if (nite(c0+i) /= 0) then
+          nnite = nnite + 1; idxnite(nnite) = i
+        end if
+      end do
+      cap_n = 0; cap_on = .true.
+      call modal_aero_sw(0, state, pbuf, nnite, idxnite(1:nnite), tau_c, wa_c, ga_c, fa_c)
+      cap_on = .false.
+      do f = 1, 5
+        nl = outfld_captured(trim(lev_names(f))//'dn', pcols, buf)
+        do i = 1, nc
+          lev(:,c0+i,f) = buf(i,1:pver)
+        end do
+        nl = outfld_captured(trim(lev_names(f)), pcols, buf)
+        do i = 1, nc
+          lev_f(:,c0+i,f) = buf(i,1:pver)
+        end do
+      end do
+      do f = 1, 23 + 3*nm
+        if (f <= 23) then
+          nm_dn = trim(col_names(f))//'dn'; nm_day = col_names(f)
+        else
+          m = (f - 24)/3 + 1
+          select case (mod(f - 24, 3))
+          case (0)
+            write(nm_dn,'(a,i2.2)') 'BURDENdn', m;  write(nm_day,'(a,i2.2)') 'BURDEN', m
+          case (1)
+            write(nm_dn,'(a,i1)') 'AODdn_mode', m;  write(nm_day,'(a,i1)') 'AOD_mode', m
+          case (2)
+            write(nm_dn,'(a,i2.2)') 'AODdnDUST', m; write(nm_day,'(a,i2.2)') 'AODDUST', m
+          end select
+        end if
+        nl = outfld_captured(trim(nm_dn), pcols, buf)
+        col(c0+1:c0+nc,f) = buf(1:nc,1)
+        nl = outfld_captured(trim(nm_day), pcols, buf)
+        col_f(c0+1:c0+nc,f) = buf(1:nc,1)
+      end do
+      c0 = c0 + nc
+    end do
+  end subroutine ref_modal_aero_sw_diag
+
   subroutine ref_modal_aero_lw(n, pdeldry, pmid, t, specmmr, dgnumwet, qaerwat, troplev, tauxar) &
        bind(C, name='ref_modal_aero_lw')
     integer(c_int), value :: n

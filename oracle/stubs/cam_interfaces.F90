@@ -69,7 +69,17 @@ end module physconst
 
 module cam_history
   use shr_kind_mod, only: r8 => shr_kind_r8
+  use ppgrid,       only: pcols, pverp
   integer, parameter :: horiz_only = 1
+  ! History output is a no-op in the oracle build, except that the test driver may switch on a capture of what the
+  ! reference hands to outfld (oracle/ref_wrap_aero.F90 reads modal_aero_sw's diagnostics back this way): the fields of
+  ! the CURRENT chunk, by name, last call wins.
+  integer, parameter :: cap_max = 128
+  logical            :: cap_on = .false.
+  integer            :: cap_n = 0
+  character(len=32)  :: cap_name(cap_max)
+  integer            :: cap_nlev(cap_max)
+  real(r8)           :: cap_val(pcols, pverp, cap_max)
   interface addfld
     module procedure addfld_1d, addfld_nd
   end interface addfld
@@ -78,7 +88,40 @@ contains
     character(len=*), intent(in) :: name
     real(r8), intent(in) :: field(..)
     integer, intent(in) :: idim, c
+    integer :: s, j
+    if (.not. cap_on) return
+    s = 0
+    do j = 1, cap_n
+      if (trim(cap_name(j)) == trim(name)) s = j
+    end do
+    if (s == 0) then
+      if (cap_n >= cap_max) return
+      cap_n = cap_n + 1; s = cap_n; cap_name(s) = name
+    end if
+    select rank (field)
+    rank (1)
+      cap_nlev(s) = 1
+      cap_val(1:size(field), 1, s) = field
+    rank (2)
+      cap_nlev(s) = size(field, 2)
+      cap_val(1:size(field, 1), 1:size(field, 2), s) = field
+    end select
   end subroutine outfld
+  ! copies the captured field `name` of the current chunk to out(1:n, 1:nlev); returns its level count, 0 if absent
+  integer function outfld_captured(name, n, out)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: n
+    real(r8), intent(out) :: out(n, pverp)
+    integer :: j
+    outfld_captured = 0
+    out = 0._r8
+    do j = 1, cap_n
+      if (trim(cap_name(j)) == trim(name)) then
+        outfld_captured = cap_nlev(j)
+        out(1:n, 1:cap_nlev(j)) = cap_val(1:n, 1:cap_nlev(j), j)
+      end if
+    end do
+  end function outfld_captured
   subroutine addfld_1d(fname, vdim_name, avgflag, units, long_name, flag_xyfill, sampling_seq, standard_name, fill_value)
     character(len=*), intent(in) :: fname, avgflag, units, long_name
     integer, intent(in) :: vdim_name

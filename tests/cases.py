@@ -201,3 +201,29 @@ def derived_fields_numpy(a, geo_oracle, dycore, nspecies):
                                        dycore=dycore, nspecies=nspecies)
     s = a["cpair"] * a["t"] + a["gravit"] * zm + a["phis"][:, None]
     return dict(pdel=pdel, rpdel=rpdel, pmid=pmid, lnpmid=lnpmid, zi=zi, zm=zm, s=s, q=q)
+
+
+# ---- modal_aero_sw history diagnostics -------------------------------------------------------------------------
+SWD_FILL = 1.0e36          # cam_history_support's fillvalue
+
+
+def swd_reference_ssavis(col, nite=None):
+    """The caller-side last step of SSAVISdn (modal_aer_opt.F90:1102-1128): the engine / the C restatement return the sum
+    of dopaer*palb; the reference divides it by aodvis AFTER aodvis' night columns have been overwritten with fillvalue.
+    Returns a copy of the packed column fields with that row finished the reference's way."""
+    from cam_nor_physics_amd import abi
+    col = np.array(col, dtype=np.float64, copy=True)
+    i_vis, i_ssa = abi.SWD_COL_FIELDS.index("AODVISdn"), abi.SWD_COL_FIELDS.index("SSAVISdn")
+    aodvis = col[i_vis].copy()
+    if nite is not None:
+        aodvis[np.asarray(nite) != 0] = SWD_FILL
+    col[i_ssa] = np.where(aodvis > 1.0e-10, col[i_ssa] / aodvis, 0.925)
+    return col
+
+
+def swd_field_names(nmodes):
+    from cam_nor_physics_amd import abi
+    names = list(abi.SWD_COL_FIELDS)
+    for m in range(1, nmodes + 1):
+        names += [f"BURDENdn{m:02d}", f"AODdn_mode{m}", f"AODdnDUST{m:02d}"]
+    return list(abi.SWD_LEV_FIELDS), names

@@ -115,6 +115,12 @@ def aero_golden(pver, ncol, seed):
     for k, v in sw.items():
         g["sw_" + k] = v
     g["lw_tauxar"] = lw["tauxar"]
+    # what modal_aero_sw hands to outfld (captured by the cam_history stand-in): "dn" fields and their day-only twins
+    nite = (np.arange(ncol) % 3 == 1).astype(np.int32)
+    dg = ref.modal_aero_sw_diag(st, aer, nite)
+    g["in_nite"] = nite
+    for k, v in dg.items():
+        g["swd_" + k] = v
     return g
 
 

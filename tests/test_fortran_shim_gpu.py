@@ -88,3 +88,12 @@ def test_fortran_optics_caller_on_hip_engine_matches_reference_golden(name):
         assert_close("modal_aero_sw." + k, sw[k], g["sw_" + k])
     lw = f.modal_aero_lw(st, aer)
     assert_close("modal_aero_lw.tauxar", lw["tauxar"], g["lw_tauxar"])
+    # the history fields the shim's modal_aero_sw hands to outfld, captured by the same cam_history stand-in that captured
+    # the reference's: "dn" set and day-only twins, night columns filled, SSAVISdn with the reference's night quirk
+    dg = f.modal_aero_sw_diag(st, aer, g["in_nite"])
+    lev_names, col_names = cases.swd_field_names(4)
+    for tag in ("", "_f"):
+        for i, nm in enumerate(lev_names):
+            assert_close(nm + tag, dg["lev" + tag][i], g["swd_lev" + tag][i])
+        for i, nm in enumerate(col_names):
+            assert_close(nm + tag, dg["col" + tag][i], g["swd_col" + tag][i])

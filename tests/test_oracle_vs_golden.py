@@ -107,6 +107,35 @@ def test_modal_aero_vs_reference_golden(name):
     assert (g["in_dgnumwet"] > 4.0e-5).any() and (g["in_qaerwat"] < 0).any()
 
 
+@pytest.mark.parametrize("name", cases.AERO_GOLDEN)
+def test_modal_aero_sw_diagnostics_vs_reference_golden(name):
+    """The history diagnostics of modal_aero_sw: the C restatement against what the reference build handed to outfld
+    (captured by the cam_history stand-in, "dn" fields), SSAVISdn finished the reference's way (night-filled aodvis)."""
+    g = cases.load_golden(name)
+    pver = g["in_t"].shape[1]
+    co = COracle(cases.default_params(pver))
+    co.aero_tables_set(synth.make_aero_props(int(g["seed"])), synth.PHYSCONST)
+    st = dict(pdeldry=g["in_pdeldry"], pmid=g["in_pmid"], t=g["in_t"])
+    aer = {k: g["in_" + k] for k in ("specmmr", "dgnumwet", "qaerwat", "troplevchem")}
+    dg = co.modal_aero_sw_diag(st, aer)
+    lev_names, col_names = cases.swd_field_names(co.tables.nmodes)
+    col = cases.swd_reference_ssavis(dg["col"], g["in_nite"])
+    for f, nm in enumerate(lev_names):
+        assert_close(nm, dg["lev"][f], g["swd_lev"][f])
+    for f, nm in enumerate(col_names):
+        assert_close(nm, col[f], g["swd_col"][f])
+    # every field is exercised (non-zero somewhere) and the stratospheric sums are proper parts of the column sums
+    assert all(np.abs(g["swd_col"][f]).max() > 0 for f in range(len(col_names)))
+    assert (g["swd_col"][3] < g["swd_col"][0]).all() and (g["swd_col"][3] > 0).any()
+    # the day-only twins differ from the "dn" fields exactly in the night columns, which carry fillvalue
+    night = g["in_nite"] != 0
+    assert night.any() and (g["swd_col_f"][:, night] == cases.SWD_FILL).all() and (g["swd_lev_f"][:, night] == cases.SWD_FILL).all()
+    i_ssa = col_names.index("SSAVISdn")
+    keep = np.ones(len(col_names), bool); keep[i_ssa] = False
+    assert np.array_equal(g["swd_col_f"][keep][:, ~night], g["swd_col"][keep][:, ~night])
+    assert np.array_equal(g["swd_lev_f"][:, ~night], g["swd_lev"][:, ~night])
+
+
 def test_golden_fixtures_cover_the_branches():
     g = cases.load_golden("zm_l32_pbl")
     nl = cases.golden_namelist(g)

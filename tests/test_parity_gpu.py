@@ -255,6 +255,39 @@ def test_modal_aero_vs_reference_golden(name, sw_kernel, monkeypatch):
     assert (sw["tauxar"] >= 0).all() and (lw["tauxar"] >= 0).all()
 
 
+def _swd_engine(eng, st, aer):
+    """modal_aero_sw followed by its history diagnostics on the engine; numpy lev / col"""
+    d = eng.dev
+    a = (d(st["pdeldry"]), d(aer["specmmr"]), d(aer["dgnumwet"]), d(aer["qaerwat"]))
+    sw = eng.modal_aero_sw(*a)
+    dg = eng.modal_aero_sw_diag(a[0], d(st["pmid"]), d(st["t"]), a[1], a[2], a[3], d(aer["troplevchem"].astype(np.int32)), sw["tauxar"])
+    return to_np(dg)
+
+
+def _assert_swd(got, want_lev, want_col, nmodes):
+    lev_names, col_names = cases.swd_field_names(nmodes)
+    for f, nm in enumerate(lev_names):
+        assert_close(nm, got["lev"][f], want_lev[f])
+    for f, nm in enumerate(col_names):
+        assert_close(nm, got["col"][f], want_col[f])
+
+
+@pytest.mark.parametrize("name", cases.AERO_GOLDEN)
+def test_modal_aero_sw_diagnostics_vs_reference_golden(name):
+    """modal_aero_sw's history diagnostics (modal_aer_opt.F90:896-993, 1046-1154) against what the reference build handed to
+    outfld ("dn" fields; SSAVISdn finished the reference's way on the caller side, cases.swd_reference_ssavis).
+    Tolerance 1e-10 relative (tests/util.py); AODTOT / UV / near-IR come from tauxar, i.e. summed over modes first."""
+    g = cases.load_golden(name)
+    pver = g["in_t"].shape[1]
+    eng = engine(cases.default_params(pver))
+    eng.aero_tables_set(synth.make_aero_props(int(g["seed"])), synth.PHYSCONST)
+    st = dict(pdeldry=g["in_pdeldry"], pmid=g["in_pmid"], t=g["in_t"])
+    aer = {k: g["in_" + k] for k in ("specmmr", "dgnumwet", "qaerwat", "troplevchem")}
+    dg = _swd_engine(eng, st, aer)
+    dg["col"] = cases.swd_reference_ssavis(dg["col"], g["in_nite"])
+    _assert_swd(dg, g["swd_lev"], g["swd_col"], eng.tables.nmodes)
+
+
 # ---------------------------------------------------------------------------------------------------
 # (b) C restatement on fresh seeded inputs, sizes the oracle finishes in seconds
 # ---------------------------------------------------------------------------------------------------
@@ -343,6 +376,58 @@ def test_modal_aero_vs_c_oracle(top_lev):
     if top_lev > 1:
         assert not sw["tauxar"][:, :, 1:top_lev].any() and not lw["tauxar"][:, :, :top_lev - 1].any()
         assert sw["tauxar"][:, :, top_lev:].all()
+
+
+@pytest.mark.parametrize("pver,ncol,top_lev", [(32, 701, 1), (32, 203, 4), (70, 100, 1), (26, 37, 2)])
+def test_modal_aero_sw_diagnostics_vs_c_oracle(pver, ncol, top_lev):
+    """ragged column counts (blocks own NT/pver columns: 8, 3, 9 per block here), top_lev > 1, tropopause anywhere
+    including above the top level and below the surface"""
+    from c_oracle import COracle
+    params = cases.default_params(pver)
+    eng = engine(params)
+    co = COracle(params)
+    props = synth.make_aero_props(12)
+    props["top_lev"] = top_lev
+    st = synth.make_state(ncol, pver, 12)
+    aer = synth.make_aero_state(ncol, pver, props, 12)
+    aer["troplevchem"] = aer["troplevchem"].astype(np.int32)
+    aer["troplevchem"][::5] = 0
+    aer["troplevchem"][1::7] = pver + 3
+    aer["qaerwat"][:, ::9, :] *= -1.0                             # negative water: watervol reset before the partition
+    eng.aero_tables_set(props, synth.PHYSCONST)
+    co.aero_tables_set(props, synth.PHYSCONST)
+    got, want = _swd_engine(eng, st, aer), co.modal_aero_sw_diag(st, aer)
+    _assert_swd(got, want["lev"], want["col"], eng.tables.nmodes)
+    if top_lev > 1:
+        assert not got["lev"][:, :, :top_lev - 1].any()
+
+
+def test_modal_aero_sw_diagnostics_identities_at_full_size():
+    """ne30 size (48 602 columns): relations that hold whatever the inputs -- the column sums are the level sums of the level
+    fields times mass / air density, the species optical depths add up to the visible one, stratospheric parts are parts"""
+    pver, ncol = 32, 48602
+    eng = engine(cases.default_params(pver))
+    props = synth.make_aero_props(3)
+    st = synth.make_state(ncol, pver, 3)
+    aer = synth.make_aero_state(ncol, pver, props, 3)
+    eng.aero_tables_set(props, synth.PHYSCONST)
+    dg = _swd_engine(eng, st, aer)
+    lev, col = dg["lev"], dg["col"]
+    mass = st["pdeldry"] * synth.PHYSCONST["rga"]
+    ad = st["pmid"] / (synth.PHYSCONST["rair"] * st["t"])
+    assert_close("AODVIS = sum extinct*mass/rho", (lev[0] * mass / ad).sum(1), col[0], rtol=1e-12)
+    assert_close("AODABS = sum absorb*mass/rho", (lev[1] * mass / ad).sum(1), col[1], rtol=1e-12)
+    assert_close("AODxASYM = sum asymext*mass/rho", (lev[2] * mass / ad).sum(1), col[5], rtol=1e-12)
+    assert_close("AODUV", (lev[3] * mass / ad).sum(1), col[6], rtol=1e-12)
+    assert_close("AODNIR", (lev[4] * mass / ad).sum(1), col[7], rtol=1e-12)
+    assert_close("species AODs add up to AODVIS", col[17:23].sum(0), col[0], rtol=1e-10)
+    nm = eng.tables.nmodes
+    assert_close("mode AODs add up to AODVIS", col[24:24 + 3 * nm:3].sum(0), col[0], rtol=1e-12)
+    assert_close("mode burdens add up to the species burdens", col[23:23 + 3 * nm:3].sum(0), col[10:16].sum(0), rtol=1e-12)
+    for part, whole in ((3, 0), (8, 6), (9, 7)):
+        assert (col[part] <= col[whole] * (1 + 1e-14)).all() and (col[part] >= 0).all()
+    assert (col[2] >= col[0]).all()                               # all bands >= the visible band
+    assert (col[4] <= col[0] * (1 + 1e-14)).all()                 # sum dopaer*palb <= sum dopaer
 
 
 def test_modal_aero_edge_branches_vs_c_oracle():
