@@ -690,6 +690,15 @@ int colphys_aero_tables_set(const colphys_aero_tables *tb)
         std::vector<double> rd(nm * ns);
         for (size_t i = 0; i < nm * ns; ++i) rd[i] = 1.0 / tb->specdens[i];
         bad |= up(rd.data(), 8 * nm * ns, (const void **)&A.rspecdens);
+        std::vector<int32_t> lm(nm, 0);
+        for (size_t m = 0; m < nm; ++m)
+            for (int l = 0; l < tb->nspec[m]; ++l) {
+                const int ty = tb->spectype[m * ns + l];
+                bool last = ty >= 0 && ty < 6;
+                for (int l2 = l + 1; last && l2 < tb->nspec[m]; ++l2) last = tb->spectype[m * ns + l2] != ty;
+                if (last) lm[m] |= 1 << l;
+            }
+        bad |= up(lm.data(), sizeof(int32_t) * nm, (const void **)&A.lastmask);
         A.rxrange = 1.0 / (tb->xrmax - tb->xrmin);
         A.nspec_total = 0;
         for (size_t m = 0; m < nm; ++m) A.nspec_total += tb->nspec[m];

@@ -54,6 +54,8 @@ struct AeroDev {
     double rxrange;                 // 1/(xrmax - xrmin)
     int nspec_total;                // sum of nspec over the modes (host mirror)
     int idx_sw_diag, idx_uv_diag, idx_nir_diag;   // radconstants' diagnostic bands, 1-based (SW history diagnostics)
+    const int *lastmask;            // [nmodes] bit l: species l is the LAST of its type (0..5) in the mode -- the one whose
+                                    // refractive index / hygroscopicity the species partition keeps (modal_aer_opt.F90:780-829)
 };
 constexpr int AERO_NCP = 6;
 constexpr int AERO_TBLP = COLPHYS_PREFI * COLPHYS_PREFR * AERO_NCP;

@@ -27,6 +27,8 @@
 // table_interp semantics: oracle/stubs/l0_arithmetic.F90 (parity-unpinned seam).
 #include "colphys_common.h"
 
+#include <algorithm>
+
 #ifndef AERO_MIN_WAVES
 #define AERO_MIN_WAVES 3                   // 3 waves / SIMD: the kernel needs ~136 VGPRs
 #endif
@@ -64,6 +66,8 @@ struct Wght { double wt1, wt2; int ix1, ix2; };
 // that could clobber any global load and turns every uniform load into a vector load waiting on vmcnt with the DMA.
 typedef const __attribute__((address_space(4))) double *cptr_t;
 __device__ __forceinline__ cptr_t as_const(const double *p) { return (cptr_t)(const void *)p; }
+typedef const __attribute__((address_space(4))) int *ciptr_t;
+__device__ __forceinline__ ciptr_t as_const(const int *p) { return (ciptr_t)(const void *)p; }
 
 // calcwghts of table_interp: first grid point above x (the reference's loop with exit), extrapolating below the
 // grid and clamping above it.  g: the grid through a wave-uniform global pointer (scalar loads -> SGPR operands);
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
     const int nunits = A.nmodes * nbg;
     int unit = 0;
     for (int m = 0; m < A.nmodes; ++m) {                                // :706 / :1328
-        const int nspec = A.nspec[m];
+        const int nspec = as_const(A.nspec)[m];
         double vol[NSMAX], dryvol = 0.0, radsurf, logradsurf, cheb[NC];
         const double dgn = io.dgnumwet[m * F + cc];
         const double qw = io.qaerwat[m * F + cc];
@@ -339,6 +343,11 @@ __global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(Ae
     int bad = 0;
 
     double cheb[NMMAX][NC], watervol[NMMAX], wetvol[NMMAX], wetinv[NMMAX], radsurf[NMMAX];
+    // species counts: scalar loads, once.  (Read as A.nspec[m] inside the band loop they were VECTOR loads of a uniform
+    // value -- global_load + s_waitcnt vmcnt(0) + v_readfirstlane at the head of every (band, mode) unit.)
+    int nsp[NMMAX];
+#pragma unroll
+    for (int m = 0; m < NMMAX; ++m) nsp[m] = (m < A.nmodes) ? as_const(A.nspec)[m] : 0;
     int voff[NMMAX + 1];
     voff[0] = 0;
     bool small[NMMAX];
@@ -349,7 +358,7 @@ __global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(Ae
 #pragma unroll
         for (int nc = 0; nc < NC; ++nc) cheb[m][nc] = 0.0;
         if (m < A.nmodes) {
-            const int nspec = A.nspec[m];
+            const int nspec = nsp[m];
             voff[m + 1] = voff[m] + nspec;
             const double dgn = io.dgnumwet[m * F + cc];
             const double qw = io.qaerwat[m * F + cc];
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(Ae
 #pragma unroll
         for (int m = 0; m < NMMAX; ++m) {
             if (m < A.nmodes) {
-                const int nspec = A.nspec[m];
+                const int nspec = nsp[m];
                 const double *s_tbl = s_slice0 + cur * SLICE;
                 const double *s_refr = s_tbl + NTAB * TBLP, *s_refi = s_refr + NR;
                 const double *s_rdxr = s_refi + NI, *s_rdxi = s_rdxr + NR;
@@ -456,28 +465,50 @@ __global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(Ae
 //     (column, field); the per-cell terms add the modes in the reference's order.
 // One slice (mode, visible band) in LDS at a time, copied by the LDS-DMA path like in the radiative kernels.
 // ------------------------------------------------------------------------------------------------------
-typedef const __attribute__((address_space(4))) int *ciptr_t;
-__device__ __forceinline__ ciptr_t as_const(const int *p) { return (ciptr_t)(const void *)p; }
-constexpr int DIAG_ROUND = 8;               // column fields reduced per LDS round
+constexpr int DIAG_ROUND = 8;               // column fields per summing pass
+constexpr int DIAG_NSLOT = 3 * DIAG_ROUND;  // per-cell terms staged per mode
+constexpr int DIAG_CPB = 8;                 // at most this many columns per block: CPB x ROUND x PARTS = NT summing threads
+constexpr int DIAG_PARTS = 4;               // threads per (column, field) sum
+constexpr int DIAG_STRIDE = NT + 4;         // slot stride in doubles: slots land on different LDS banks for the summing reads
 constexpr int NTYPE = 6;                    // sulfate, p-organic, s-organic, black-c, dust, seasalt (include/colphys.h)
+#ifndef DIAG_WAVES
+#define DIAG_WAVES 2                        // waves per SIMD the register budget is set for
+#endif
 
-// ordered sum over the levels of field slot j of column cl, by one thread
-__device__ __forceinline__ double level_sum(const double *s_red, int j, int cl, int pver)
+// Column sums of one pass: every thread has stored its cell's terms in s[slot][DIAG_STRIDE]; thread (column rc, slot j of
+// the pass, part q) adds the levels q, q+4, ... of its column in order and the four parts are added as (p0 + p1) + (p2 + p3).
+// Every thread of a group returns the sum.  No barrier inside.
+__device__ __forceinline__ double level_sums(const double *s, int nred, int pver)
 {
-    const double *p = s_red + j * NT + cl * pver;
+    const int tid = threadIdx.x;
+    const int q = tid & (DIAG_PARTS - 1), j = (tid >> 2) & (DIAG_ROUND - 1), rc = tid >> 5;
     double a = 0.0;
-    for (int k = 0; k < pver; ++k) a = a + p[k];
+    if (rc < nred) {
+        const double *p = s + j * DIAG_STRIDE + rc * pver;
+        for (int k = q; k < pver; k += DIAG_PARTS) a = a + p[k];
+    }
+    a = a + __shfl_xor(a, 1);
+    a = a + __shfl_xor(a, 2);
     return a;
 }
 
-__global__ __launch_bounds__(NT, 2) void modal_aero_sw_diag_kernel(AeroDev A, int ncol, int pver, int cpb, colphys_modal_aero_io io,
-                                                                 double *__restrict__ lev, double *__restrict__ colf)
+// slots of the three per-mode rounds -> column field (-1: a per-mode field or unused)
+__device__ __constant__ int diag_slot_field[3 * DIAG_ROUND] = {
+    COLPHYS_SWD_COL_AODVIS, COLPHYS_SWD_COL_AODABS, COLPHYS_SWD_COL_SSAVIS, COLPHYS_SWD_COL_ASYMVIS, COLPHYS_SWD_COL_AODABSBC,
+    COLPHYS_SWD_COL_AODVISST, -1, -1,
+    COLPHYS_SWD_COL_BURDEN0, COLPHYS_SWD_COL_BURDEN0 + 1, COLPHYS_SWD_COL_BURDEN0 + 2, COLPHYS_SWD_COL_BURDEN0 + 3,
+    COLPHYS_SWD_COL_BURDEN0 + 4, COLPHYS_SWD_COL_BURDEN0 + 5, -1, -1,
+    COLPHYS_SWD_COL_AOD0, COLPHYS_SWD_COL_AOD0 + 1, COLPHYS_SWD_COL_AOD0 + 2, COLPHYS_SWD_COL_AOD0 + 3, COLPHYS_SWD_COL_AOD0 + 4,
+    COLPHYS_SWD_COL_AOD0 + 5, -1, -1};
+
+__global__ __launch_bounds__(NT, DIAG_WAVES) void modal_aero_sw_diag_kernel(AeroDev A, int ncol, int pver, int cpb, colphys_modal_aero_io io,
+                                                                             double *__restrict__ lev, double *__restrict__ colf)
 {
     constexpr int NTAB = 3;
     constexpr int SLICE = aero_slice_doubles(NTAB);
     extern __shared__ double smem[];
-    double *s_tbl = smem;                              // the (mode, visible band) slice
-    double *s_red = smem + SLICE;                      // [DIAG_ROUND][NT] per-cell terms of the fields being summed
+    double *s_slice0 = smem;                           // the (mode, visible band) slices, double-buffered
+    double *s_red = smem + 2 * SLICE;                  // [DIAG_NSLOT][DIAG_STRIDE] per-cell terms of the fields being summed
 
     const int nb = A.nswbands, ivis = A.idx_sw_diag - 1;
     const size_t L = (size_t)pver, F = (size_t)ncol * L, LP = L + 1;
@@ -490,73 +521,69 @@ __global__ __launch_bounds__(NT, 2) void modal_aero_sw_diag_kernel(AeroDev A, in
     const bool active = live && k >= A.top_lev;
     const double rh2odens = 1.0 / A.rhoh2o;
     const double *slices = A.slices_sw;
+    // summing role of this thread (level_sums): column rc of the block, slot j of a round, part q
+    const int sq = tid & (DIAG_PARTS - 1), sj = (tid >> 2) & (DIAG_ROUND - 1), src = tid >> 5;
+    const int nred = min(cpb, ncol - (int)blockIdx.x * cpb);            // columns of this block that exist
+    const bool writer = sq == 0 && src < nred;
+    const size_t wcol = (size_t)blockIdx.x * cpb + src;
 
-    const double pdel = io.pdeldry[cc];
-    const double mass = pdel * A.rga;                                   // :644
+    slice_issue<SLICE>(slices + (size_t)ivis * SLICE, s_slice0);       // mode 0
+
+    const double mass = io.pdeldry[cc] * A.rga;                         // :644
     const double air_density = io.pmid[cc] / (A.rair * io.t[cc]);       // :645
+    const double ad_mass = air_density / mass;                          // x*air_density/mass (:901, 911, 924, 931) as one product
     const bool strat = live && k <= io.troplevchem[live ? col : 0];     // :903, 913, 932
 
-    // column totals over all bands / in the UV and near-IR bands from the radiative kernel's tauxar
-    double t_tot = 0.0, t_uv = 0.0, t_nir = 0.0;
-    if (active) {
-        const double *tau = io.tauxar + (size_t)col * nb * LP + k;
-        for (int ib = 0; ib < nb; ++ib) t_tot = t_tot + tau[(size_t)ib * LP];
-        t_uv = tau[(size_t)(A.idx_uv_diag - 1) * LP];
-        t_nir = tau[(size_t)(A.idx_nir_diag - 1) * LP];
-    }
+    double extinct = 0.0, absorb = 0.0, asymext = 0.0;                  // level fields: the cell's sums over the modes
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;                          // summing threads: column sums over the modes, one per round
 
-    // per-cell sums over the modes (reference order of the modes)
-    double extinct = 0.0, absorb = 0.0, asymext = 0.0;
-    double c_aodvis = 0.0, c_aodabs = 0.0, c_ssavis = 0.0, c_asymvis = 0.0, c_aodabsbc = 0.0;
-    double c_burden[NTYPE], c_aod[NTYPE];
+    // A mode's cell inputs are loaded one mode ahead, right AFTER the barrier that waits for the slice: LDS-DMA and global
+    // loads share vmcnt, so anything issued before that barrier is waited for at it; issued after it, the loads have the
+    // whole table / partition phase of the current mode to land (two waves per SIMD hide little by themselves).
+    double n_v[NSMAX], n_dgn, n_qw;
+    auto load_mode = [&](int m) {
+        const int nspec = as_const(A.nspec)[m];
+        n_dgn = io.dgnumwet[m * F + cc];
+        n_qw = io.qaerwat[m * F + cc];
 #pragma unroll
-    for (int ty = 0; ty < NTYPE; ++ty) { c_burden[ty] = 0.0; c_aod[ty] = 0.0; }
+        for (int l = 0; l < NSMAX; ++l) {
+            n_v[l] = 0.0;
+            if (l < nspec) n_v[l] = io.specmmr[((size_t)m * A.nspec_max + l) * F + cc];
+        }
+    };
+    load_mode(0);
 
-    const int nred = min(cpb, ncol - (int)blockIdx.x * cpb);            // columns of this block that exist
-
+    int cur = 0;
     for (int m = 0; m < A.nmodes; ++m) {                                // :706
-        const int nspec = A.nspec[m];
-        slice_issue<SLICE>(slices + ((size_t)m * nb + ivis) * SLICE, s_tbl);
+        const int nspec = as_const(A.nspec)[m];
+        const double *s_tbl = s_slice0 + cur * SLICE;
         const double *s_refr = s_tbl + NTAB * TBLP, *s_refi = s_refr + NR;
         const double *s_rdxr = s_refi + NI, *s_rdxi = s_rdxr + NR;
 
         double v[NSMAX], radsurf, logradsurf, cheb[NC];
-        const double dgn = io.dgnumwet[m * F + cc];
-        const double qw = io.qaerwat[m * F + cc];
+        const double dgn = n_dgn, qw = n_qw;
 #pragma unroll
-        for (int l = 0; l < NSMAX; ++l) {
-            v[l] = 0.0;
-            if (l < nspec) v[l] = io.specmmr[((size_t)m * A.nspec_max + l) * F + cc];
-        }
+        for (int l = 0; l < NSMAX; ++l) v[l] = n_v[l];
         size_parameters(A, as_const(A.explnsigma)[m], dgn, radsurf, logradsurf, cheb);
 
-        // species loop :758-832 at the visible band
+        // species loop :758-768 at the visible band; v[l] becomes the species volume
         cptr_t ri = as_const(A.specrefindex_sw + ((size_t)m * A.nspec_max * nb + ivis) * 2);
-        double cre = 0.0, cim = 0.0, dryvol = 0.0, dustvol = 0.0, burden = 0.0;
-        double scat[NTYPE], absb[NTYPE], hyg[NTYPE];
+        double cre = 0.0, cim = 0.0, dryvol = 0.0, burden = 0.0;
+        double bur[NTYPE];
 #pragma unroll
-        for (int ty = 0; ty < NTYPE; ++ty) { scat[ty] = 0.0; absb[ty] = 0.0; hyg[ty] = 0.0; }
+        for (int ty = 0; ty < NTYPE; ++ty) bur[ty] = 0.0;
 #pragma unroll
         for (int l = 0; l < NSMAX; ++l) {
             if (l < nspec) {
-                const double vol = v[l] * as_const(A.rspecdens)[m * A.nspec_max + l];   // :765 as a product, like the radiative kernel
-                const double re = ri[(size_t)l * nb * 2], im = ri[(size_t)l * nb * 2 + 1];
-                dryvol = dryvol + vol;
-                cre = cre + vol * re;
-                cim = cim + vol * im;
-                const double bm = v[l] * mass;                          // :777
+                const double bm = active ? v[l] * mass : 0.0;           // :777
                 burden = burden + bm;
                 const int sty = as_const(A.spectype)[m * A.nspec_max + l];
-                const double hy = as_const(A.hygro)[m * A.nspec_max + l];
 #pragma unroll
-                for (int ty = 0; ty < NTYPE; ++ty) {                    // :780-829; sty is wave-uniform
-                    const bool is = (sty == ty);
-                    c_burden[ty] = c_burden[ty] + (is && active ? bm : 0.0);
-                    scat[ty] = is ? vol * re : scat[ty];                // assignments: the last species of a type stays
-                    absb[ty] = is ? -(vol * im) : absb[ty];
-                    hyg[ty] = is ? vol * hy : hyg[ty];
-                }
-                dustvol = (sty == 4) ? vol : dustvol;
+                for (int ty = 0; ty < NTYPE; ++ty) bur[ty] = bur[ty] + ((sty == ty) ? 1.0 : 0.0) * bm;   // :782-824, scalar weights
+                v[l] = v[l] * as_const(A.rspecdens)[m * A.nspec_max + l];     // :765 as a product, like the radiative kernel
+                dryvol = dryvol + v[l];
+                cre = cre + v[l] * ri[(size_t)l * nb * 2];
+                cim = cim + v[l] * ri[(size_t)l * nb * 2 + 1];
             }
         }
         double watervol = qw * rh2odens;                                // :835-844
@@ -570,7 +597,11 @@ __global__ __launch_bounds__(NT, 2) void modal_aero_sw_diag_kernel(AeroDev A, in
         cim = (cim + watervol * cwi) * wetinv;
         const double refr = cre, refi = fabs(cim);
 
-        __syncthreads();                                                // the slice has landed
+        __syncthreads();                                                // this mode's slice has landed; the other buffer is free
+        if (m + 1 < A.nmodes) {
+            slice_issue<SLICE>(slices + ((size_t)(m + 1) * nb + ivis) * SLICE, s_slice0 + (cur ^ 1) * SLICE);
+            load_mode(m + 1);
+        }
         cptr_t g_grid = as_const(slices + ((size_t)m * nb + ivis) * SLICE + NTAB * TBLP);
         const Wght wr = calcwghts<NR>(g_grid, s_refr, s_rdxr, refr);    // :857-862
         const Wght wi = calcwghts<NI>(g_grid + NR, s_refi, s_rdxi, refi);
@@ -578,49 +609,84 @@ __global__ __launch_bounds__(NT, 2) void modal_aero_sw_diag_kernel(AeroDev A, in
         double pabs = interp_cheb(s_tbl + TBLP, wr, wi, cheb);
         const double pasm = interp_cheb(s_tbl + 2 * TBLP, wr, wi, cheb);
         const double pe = exp(pext);                                    // :869-877
-        pext = small ? pe : 1.5 / (radsurf * A.rhoh2o);
+        if (!small) pext = 1.5 / (radsurf * A.rhoh2o); else pext = pe;
         pext = pext * wetvol * A.rhoh2o;                                // :881-894
         pabs = pabs * wetvol * A.rhoh2o;
         pabs = fmax(0.0, pabs);
         pabs = fmin(pext, pabs);
         const double palb = 1.0 - pabs / fmax(pext, 1.e-40);
-        const double dopaer = pext * mass;
+        const double dopaer = active ? pext * mass : 0.0;
 
-        // :921-934
-        extinct = extinct + dopaer * air_density / mass;
+        extinct = extinct + dopaer * ad_mass;                           // :921-934
         absorb = absorb + pabs * air_density;
-        asymext = asymext + dopaer * pasm * air_density / mass;
-        double dustaod_m = 0.0;
-        if (active) {
-            c_aodvis = c_aodvis + dopaer;
-            c_aodabs = c_aodabs + pabs * mass;
-            c_ssavis = c_ssavis + dopaer * palb;
-            c_asymvis = c_asymvis + dopaer * pasm;
-            if (wetvol > 1.e-40) {                                      // :936-990
-                dustaod_m = dopaer * dustvol / wetvol;
-                const double scath2o = watervol * cwr, absh2o = -(watervol * cwi);
-                const double sumscat = scat[0] + scat[1] + scat[2] + scat[3] + scat[4] + scat[5] + scath2o;
-                const double sumabs = absb[0] + absb[1] + absb[2] + absb[3] + absb[4] + absb[5] + absh2o;
-                const double sumhygro = hyg[0] + hyg[1] + hyg[2] + hyg[3] + hyg[4] + hyg[5];
+        asymext = asymext + dopaer * pasm * ad_mass;
+
+        // per-cell terms of this mode: slots 0..5 plain visible-band sums, 6, 7 two of the three per-mode fields
+        // (:1050-1057; the third, aodmode, is slot 0), 8..13 burdens by type, 16..21 optical depths by type
+        s_red[0 * DIAG_STRIDE + tid] = dopaer;                          // aodvis, aodmode
+        s_red[1 * DIAG_STRIDE + tid] = active ? pabs * mass : 0.0;      // aodabs
+        s_red[2 * DIAG_STRIDE + tid] = dopaer * palb;                   // ssavis
+        s_red[3 * DIAG_STRIDE + tid] = dopaer * pasm;                   // asymvis
+        s_red[5 * DIAG_STRIDE + tid] = strat ? dopaer : 0.0;            // aodvisst
+        s_red[6 * DIAG_STRIDE + tid] = burden;
 #pragma unroll
-                for (int ty = 0; ty < NTYPE; ++ty) {
-                    const double sc = (scat[ty] + scath2o * hyg[ty] / sumhygro) / sumscat;
-                    const double ab = (absb[ty] + absh2o * hyg[ty] / sumhygro) / sumabs;
-                    if (ty == 3) c_aodabsbc = c_aodabsbc + ab * dopaer * (1.0 - palb);      // :970
-                    c_aod[ty] = c_aod[ty] + (ab * (1.0 - palb) + palb * sc) * dopaer;       // :972-988
+        for (int ty = 0; ty < NTYPE; ++ty) s_red[(DIAG_ROUND + ty) * DIAG_STRIDE + tid] = bur[ty];
+
+        // species partition :936-990.  Only the LAST species of a type enters (the reference assigns, :783-827).
+        // sums first, then each kept species' share straight into its type's term (scalar 0/1 weights: sty is uniform)
+        double aod[NTYPE], absbc = 0.0, dustaod_m = 0.0;
+#pragma unroll
+        for (int ty = 0; ty < NTYPE; ++ty) aod[ty] = 0.0;
+        if (wetvol > 1.e-40) {
+            const int lastmask = as_const(A.lastmask)[m];
+            const double scath2o = watervol * cwr, absh2o = -(watervol * cwi);
+            double sumscat = 0.0, sumabs = 0.0, sumhygro = 0.0;
+#pragma unroll
+            for (int l = 0; l < NSMAX; ++l) {
+                if (l < nspec && ((lastmask >> l) & 1)) {
+                    sumscat = sumscat + v[l] * ri[(size_t)l * nb * 2];
+                    sumabs = sumabs - v[l] * ri[(size_t)l * nb * 2 + 1];
+                    sumhygro = sumhygro + v[l] * as_const(A.hygro)[m * A.nspec_max + l];
+                }
+            }
+            sumscat = sumscat + scath2o;
+            sumabs = sumabs + absh2o;
+            // the eighteen quotients of :952-968 as products with three reciprocals
+            const double rscat = 1.0 / sumscat, rabs = 1.0 / sumabs, rhyg = 1.0 / sumhygro;
+            const double wsc = scath2o * rhyg, wab = absh2o * rhyg;
+            const double ssa_d = palb * dopaer * rscat, abs_d = (1.0 - palb) * dopaer * rabs;
+#pragma unroll
+            for (int l = 0; l < NSMAX; ++l) {
+                if (l < nspec && ((lastmask >> l) & 1)) {
+                    const int sty = as_const(A.spectype)[m * A.nspec_max + l];
+                    const double hy = as_const(A.hygro)[m * A.nspec_max + l];
+                    const double ab = (wab * hy - ri[(size_t)l * nb * 2 + 1]) * v[l] * abs_d;       // absX*(1-palb)*dopaer, :953-972
+                    const double sc = (wsc * hy + ri[(size_t)l * nb * 2]) * v[l] * ssa_d;           // scatX*palb*dopaer
+#pragma unroll
+                    for (int ty = 0; ty < NTYPE; ++ty) aod[ty] = aod[ty] + ((sty == ty) ? 1.0 : 0.0) * (ab + sc);
+                    absbc = absbc + ((sty == 3) ? 1.0 : 0.0) * ab;      // :970
+                    dustaod_m = dustaod_m + ((sty == 4) ? 1.0 : 0.0) * (dopaer * v[l] * wetinv);   // :938, /wetvol = *wetinv here
                 }
             }
         }
-        // the three per-mode column fields :1050-1057
-        s_red[0 * NT + tid] = active ? burden : 0.0;
-        s_red[1 * NT + tid] = active ? dopaer : 0.0;
-        s_red[2 * NT + tid] = dustaod_m;
-        __syncthreads();                                                // also: every thread is done with the slice
-        if (tid < nred * COLPHYS_SWD_NMODEF) {
-            const int rc = tid / COLPHYS_SWD_NMODEF, j = tid - rc * COLPHYS_SWD_NMODEF;
-            colf[(size_t)(COLPHYS_SWD_NCOL + COLPHYS_SWD_NMODEF * m + j) * ncol + (size_t)blockIdx.x * cpb + rc] = level_sum(s_red, j, rc, pver);
-        }
+        s_red[4 * DIAG_STRIDE + tid] = absbc;
+        s_red[7 * DIAG_STRIDE + tid] = dustaod_m;
+#pragma unroll
+        for (int ty = 0; ty < NTYPE; ++ty) s_red[(2 * DIAG_ROUND + ty) * DIAG_STRIDE + tid] = aod[ty];
         __syncthreads();
+        {
+            const double a = level_sums(s_red, nred, pver);
+            if (sj < 6) acc0 = acc0 + a;
+            if (writer && sj == 0) colf[(size_t)(COLPHYS_SWD_NCOL + COLPHYS_SWD_NMODEF * m + 1) * ncol + wcol] = a;    // aodmode
+            if (writer && sj == 6) colf[(size_t)(COLPHYS_SWD_NCOL + COLPHYS_SWD_NMODEF * m + 0) * ncol + wcol] = a;    // burden
+            if (writer && sj == 7) colf[(size_t)(COLPHYS_SWD_NCOL + COLPHYS_SWD_NMODEF * m + 2) * ncol + wcol] = a;    // dustaodmode
+            if (sj < NTYPE) {
+                acc1 = acc1 + level_sums(s_red + DIAG_ROUND * DIAG_STRIDE, nred, pver);
+                acc2 = acc2 + level_sums(s_red + 2 * DIAG_ROUND * DIAG_STRIDE, nred, pver);
+            }
+        }
+        // (the next mode's first barrier -- its slice -- also orders these reads before the next stores)
+        cur ^= 1;
     }
 
     if (live) {
@@ -628,40 +694,59 @@ __global__ __launch_bounds__(NT, 2) void modal_aero_sw_diag_kernel(AeroDev A, in
         lev[(size_t)COLPHYS_SWD_LEV_EXTINCT * F + o] = active ? extinct : 0.0;
         lev[(size_t)COLPHYS_SWD_LEV_ABSORB * F + o] = active ? absorb : 0.0;
         lev[(size_t)COLPHYS_SWD_LEV_ASYMEXT * F + o] = active ? asymext : 0.0;
-        lev[(size_t)COLPHYS_SWD_LEV_EXTINCTUV * F + o] = active ? t_uv * air_density / mass : 0.0;
-        lev[(size_t)COLPHYS_SWD_LEV_EXTINCTNIR * F + o] = active ? t_nir * air_density / mass : 0.0;
     }
+    if (writer) {
+        const int f0 = diag_slot_field[sj], f1 = diag_slot_field[DIAG_ROUND + sj], f2 = diag_slot_field[2 * DIAG_ROUND + sj];
+        if (f0 >= 0) colf[(size_t)f0 * ncol + wcol] = acc0;
+        if (f1 >= 0) colf[(size_t)f1 * ncol + wcol] = acc1;
+        if (f2 >= 0) colf[(size_t)f2 * ncol + wcol] = acc2;
+    }
+}
 
-    // the 23 column fields in three rounds of eight
-    double term[3 * DIAG_ROUND];
-#pragma unroll
-    for (int j = 0; j < 3 * DIAG_ROUND; ++j) term[j] = 0.0;
-    term[COLPHYS_SWD_COL_AODVIS] = c_aodvis;
-    term[COLPHYS_SWD_COL_AODABS] = c_aodabs;
-    term[COLPHYS_SWD_COL_AODTOT] = t_tot;
-    term[COLPHYS_SWD_COL_AODVISST] = strat ? c_aodvis : 0.0;
-    term[COLPHYS_SWD_COL_SSAVIS] = c_ssavis;
-    term[COLPHYS_SWD_COL_ASYMVIS] = c_asymvis;
-    term[COLPHYS_SWD_COL_AODUV] = t_uv;
-    term[COLPHYS_SWD_COL_AODNIR] = t_nir;
-    term[COLPHYS_SWD_COL_AODUVST] = strat ? t_uv : 0.0;
-    term[COLPHYS_SWD_COL_AODNIRST] = strat ? t_nir : 0.0;
-#pragma unroll
-    for (int ty = 0; ty < NTYPE; ++ty) {
-        term[COLPHYS_SWD_COL_BURDEN0 + ty] = c_burden[ty];
-        term[COLPHYS_SWD_COL_AOD0 + ty] = c_aod[ty];
+// AODTOT and the UV / near-IR fields (:896-917): sums over the modes of dopaer, i.e. the radiative kernel's tauxar.  A
+// streaming kernel of its own (same block shape and column sums as above) so that its fourteen loads per cell do not
+// sit behind the table work in the two-waves-per-SIMD kernel above.
+__global__ __launch_bounds__(NT) void modal_aero_sw_diag_tau_kernel(AeroDev A, int ncol, int pver, int cpb, colphys_modal_aero_io io,
+                                                                     double *__restrict__ lev, double *__restrict__ colf)
+{
+    __shared__ double s_red[5 * DIAG_STRIDE];
+    const int nb = A.nswbands;
+    const size_t L = (size_t)pver, F = (size_t)ncol * L, LP = L + 1;
+    const int tid = threadIdx.x;
+    const int cl = tid / pver, k = tid - cl * pver + 1;
+    const int col = blockIdx.x * cpb + cl;
+    const bool live = cl < cpb && col < ncol;
+    const bool active = live && k >= A.top_lev;
+    const int sq = tid & (DIAG_PARTS - 1), sj = (tid >> 2) & (DIAG_ROUND - 1), src = tid >> 5;
+    const int nred = min(cpb, ncol - (int)blockIdx.x * cpb);
+    double t_tot = 0.0, t_uv = 0.0, t_nir = 0.0;
+    bool strat = false;
+    if (active) {
+        const size_t cc = (size_t)col * L + (k - 1);
+        const double *tau = io.tauxar + (size_t)col * nb * LP + k;
+        for (int ib = 0; ib < nb; ++ib) t_tot = t_tot + tau[(size_t)ib * LP];
+        t_uv = tau[(size_t)(A.idx_uv_diag - 1) * LP];
+        t_nir = tau[(size_t)(A.idx_nir_diag - 1) * LP];
+        strat = k <= io.troplevchem[col];                                // :903, 913
+        const double ad_mass = io.pmid[cc] / (A.rair * io.t[cc]) / (io.pdeldry[cc] * A.rga);   // air_density/mass :644-645, 901, 911
+        lev[(size_t)COLPHYS_SWD_LEV_EXTINCTUV * F + cc] = t_uv * ad_mass;
+        lev[(size_t)COLPHYS_SWD_LEV_EXTINCTNIR * F + cc] = t_nir * ad_mass;
+    } else if (live) {
+        const size_t cc = (size_t)col * L + (k - 1);
+        lev[(size_t)COLPHYS_SWD_LEV_EXTINCTUV * F + cc] = 0.0;
+        lev[(size_t)COLPHYS_SWD_LEV_EXTINCTNIR * F + cc] = 0.0;
     }
-    term[COLPHYS_SWD_COL_AODABSBC] = c_aodabsbc;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int j = 0; j < DIAG_ROUND; ++j) s_red[j * NT + tid] = term[r * DIAG_ROUND + j];
-        __syncthreads();
-        if (tid < nred * DIAG_ROUND) {
-            const int rc = tid / DIAG_ROUND, j = tid - rc * DIAG_ROUND, f = r * DIAG_ROUND + j;
-            if (f < COLPHYS_SWD_NCOL) colf[(size_t)f * ncol + (size_t)blockIdx.x * cpb + rc] = level_sum(s_red, j, rc, pver);
-        }
-        __syncthreads();
+    s_red[0 * DIAG_STRIDE + tid] = t_tot;
+    s_red[1 * DIAG_STRIDE + tid] = t_uv;
+    s_red[2 * DIAG_STRIDE + tid] = t_nir;
+    s_red[3 * DIAG_STRIDE + tid] = strat ? t_uv : 0.0;
+    s_red[4 * DIAG_STRIDE + tid] = strat ? t_nir : 0.0;
+    __syncthreads();
+    if (sj < 5) {
+        const double a = level_sums(s_red, nred, pver);
+        const int f = sj == 0 ? COLPHYS_SWD_COL_AODTOT : sj == 1 ? COLPHYS_SWD_COL_AODUV : sj == 2 ? COLPHYS_SWD_COL_AODNIR
+                    : sj == 3 ? COLPHYS_SWD_COL_AODUVST : COLPHYS_SWD_COL_AODNIRST;
+        if (sq == 0 && src < nred) colf[(size_t)f * ncol + (size_t)blockIdx.x * cpb + src] = a;
     }
 }
 
@@ -723,9 +808,13 @@ int launch_modal_aero_sw_diag(const AeroDev &A, int ncol, int pver, const colphy
                               hipStream_t st)
 {
     if (A.nspec_max > NSMAX || pver > NT) return COLPHYS_ERR_UNSUPPORTED;
-    const int cpb = NT / pver;
-    const size_t lds = ((size_t)aero_slice_doubles(3) + (size_t)DIAG_ROUND * NT) * sizeof(double);
+    const int cpb = std::min(NT / pver, DIAG_CPB);
+    const size_t lds = (2 * (size_t)aero_slice_doubles(3) + (size_t)DIAG_NSLOT * DIAG_STRIDE) * sizeof(double);
+    if (lds > 160 * 1024) return COLPHYS_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024)
+        hipFuncSetAttribute((const void *)modal_aero_sw_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const dim3 grid((unsigned)((ncol + cpb - 1) / cpb));
     hipLaunchKernelGGL(modal_aero_sw_diag_kernel, grid, dim3(NT), lds, st, A, ncol, pver, cpb, io, lev, col);
+    hipLaunchKernelGGL(modal_aero_sw_diag_tau_kernel, grid, dim3(NT), 0, st, A, ncol, pver, cpb, io, lev, col);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
