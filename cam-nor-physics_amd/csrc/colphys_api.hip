@@ -9,6 +9,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <limits>
 #include <vector>
 
 #include "colphys_common.h"
@@ -650,6 +651,43 @@ int colphys_aero_tables_set(const colphys_aero_tables *tb)
     bad |= up(tb->crefwlw, 8 * nlw * 2, (const void **)&A.crefwlw);
     if (bad) return fail(COLPHYS_ERR_HIP, "uploading aerosol tables failed (null table or hipMalloc)");
     // packed slices (see AeroDev): table element (m, ib, ii, ir, nc) -> slice[t][(ii*PREFR + ir)*AERO_NCP + nc]
+    // interval lookup of one grid (colphys_common.h, AERO_LUTB): false if two grid points would share a bucket
+    auto build_lut = [](const double *g, int n, double *gin, unsigned char *cnt, int32_t *base, int32_t *shift) -> bool {
+        auto hi32 = [](double x) -> int64_t { int64_t b; std::memcpy(&b, &x, 8); return b >> 32; };
+        auto bucket = [&](double x, int64_t bs, int sh) -> int {
+            int64_t h = hi32(x);
+            if (h < 0) h = 0;
+            int64_t b = (h - bs) >> sh;
+            return (int)std::min<int64_t>(std::max<int64_t>(b, 0), AERO_LUTB - 1);
+        };
+        for (int j = 0; j < n; ++j)
+            if (!(g[j] == g[j]) || g[j] < 0.0 || (j > 0 && !(g[j] > g[j - 1]))) return false;     // NaN, negative, not ascending
+        // the first point may sit arbitrarily far below the rest (an imaginary-index grid starting at 0): it takes bucket 0
+        // alone, the second point is put into bucket 1 and the last one must not pass the top bucket
+        const int64_t h2 = hi32(g[n > 1 ? 1 : 0]), hn = hi32(g[n - 1]);
+        for (int sh = 0; sh <= 30; ++sh) {
+            const int64_t bs = h2 - ((int64_t)1 << sh);
+            if (bs < 0) break;                                   // the kernels subtract in 32 bits from a non-negative word
+            if (((hn - bs) >> sh) > AERO_LUTB - 1) continue;
+            bool ok = true;
+            for (int j = 1; j < n && ok; ++j) ok = bucket(g[j], bs, sh) != bucket(g[j - 1], bs, sh);
+            if (!ok) return false;                               // coarser buckets only merge more
+            for (int b = 0; b < AERO_LUTB; ++b) {
+                gin[b] = std::numeric_limits<double>::infinity();
+                int below = 0;
+                for (int j = 0; j < n; ++j) {
+                    const int bj = bucket(g[j], bs, sh);
+                    if (bj < b) ++below;
+                    if (bj == b) gin[b] = g[j];
+                }
+                cnt[b] = (unsigned char)below;
+            }
+            *base = (int32_t)bs; *shift = sh;
+            return true;
+        }
+        return false;
+    };
+    bool lut_all_ok = true;
     auto pack = [&](int ntab, const double *const *tabs, const double *refr, const double *refi, size_t nbnd,
                     const double **dst) -> int {
         const size_t sl = (size_t)aero_slice_doubles(ntab), corners = (size_t)COLPHYS_PREFI * COLPHYS_PREFR;
@@ -672,13 +710,26 @@ int colphys_aero_tables_set(const colphys_aero_tables *tb)
                 const double dx = g[COLPHYS_PREFR + j + 1] - g[COLPHYS_PREFR + j];
                 r[COLPHYS_PREFR + j] = std::fabs(dx) > 1.e-20 ? 1.0 / dx : 0.0;
             }
+            double *lut = o + aero_lut_offset(ntab);
+            unsigned char *cnt = reinterpret_cast<unsigned char *>(lut + 2 * AERO_LUTB);
+            int32_t *par = reinterpret_cast<int32_t *>(lut + 2 * AERO_LUTB + 2 * AERO_LUTB / 8);
+            const bool ok = build_lut(g, COLPHYS_PREFR, lut, cnt, par + 0, par + 1) &&
+                            build_lut(g + COLPHYS_PREFR, COLPHYS_PREFI, lut + AERO_LUTB, cnt + AERO_LUTB, par + 2, par + 3);
+            par[4] = ok ? 1 : 0;
+            lut_all_ok = lut_all_ok && ok;
         }
         return up(h.data(), h.size() * sizeof(double), (const void **)dst);
     };
     {
         const double *sw_t[3] = {tb->extpsw, tb->abspsw, tb->asmpsw}, *lw_t[1] = {tb->absplw};
+        const char *nolut = getenv("COLPHYS_AERO_NO_LUT");      // tests: force the linear grid search
+        const bool want = !(nolut && atoi(nolut));
+        lut_all_ok = true;
         bad |= pack(3, sw_t, tb->refrtabsw, tb->refitabsw, nsw, &A.slices_sw);
+        A.lut_ok_sw = lut_all_ok && want;
+        lut_all_ok = true;
         bad |= pack(1, lw_t, tb->refrtablw, tb->refitablw, nlw, &A.slices_lw);
+        A.lut_ok_lw = lut_all_ok && want;
     }
     {
         std::vector<double> e(nm);

@@ -54,14 +54,27 @@ struct AeroDev {
     double rxrange;                 // 1/(xrmax - xrmin)
     int nspec_total;                // sum of nspec over the modes (host mirror)
     int idx_sw_diag, idx_uv_diag, idx_nir_diag;   // radconstants' diagnostic bands, 1-based (SW history diagnostics)
+    int lut_ok_sw, lut_ok_lw;       // every SW / LW slice has an interval lookup (host mirror)
     const int *lastmask;            // [nmodes] bit l: species l is the LAST of its type (0..5) in the mode -- the one whose
                                     // refractive index / hygroscopicity the species partition keeps (modal_aer_opt.F90:780-829)
 };
 constexpr int AERO_NCP = 6;
 constexpr int AERO_TBLP = COLPHYS_PREFI * COLPHYS_PREFR * AERO_NCP;
+// Interval lookup of table_interp's grid search (first grid point above x), per grid of a slice: a bucket index is cut
+// from the HIGH WORD of x -- b = clamp((max(hi32(x), 0) - base) >> shift, 0, AERO_LUTB-1), monotone in x, roughly
+// logarithmic across binades and linear inside one, which suits both the linear real-index grids and the geometric
+// imaginary-index grids of the modal optics files -- chosen on the host so that no bucket holds more than one grid point.
+// Then  #{j : g_j <= x} = cnt[b] + (x >= gin[b]),  cnt[b] = grid points in lower buckets, gin[b] = the grid point inside
+// bucket b (+inf if none): one compare instead of one per grid point, and the grid leaves the SGPRs.
+// Slice image after the tables and the four grid arrays: gin_r[LUTB], gin_i[LUTB] doubles; cnt_r[LUTB], cnt_i[LUTB]
+// bytes; int32 base_r, shift_r, base_i, shift_i, ok (ok = 0: some bucket would hold two points -> the kernels' linear
+// search is used for the whole table set).
+constexpr int AERO_LUTB = 32;
+constexpr int AERO_LUT_DOUBLES = 2 * AERO_LUTB + 2 * AERO_LUTB / 8 + 3;
+constexpr int aero_lut_offset(int ntab) { return ntab * AERO_TBLP + 2 * (COLPHYS_PREFR + COLPHYS_PREFI); }
 constexpr int aero_slice_doubles(int ntab)
 {
-    return ((ntab * AERO_TBLP + 2 * (COLPHYS_PREFR + COLPHYS_PREFI)) * 8 + 1023) / 1024 * 128;
+    return ((aero_lut_offset(ntab) + AERO_LUT_DOUBLES) * 8 + 1023) / 1024 * 128;
 }
 
 // ---- division ---------------------------------------------------------------------------------------------

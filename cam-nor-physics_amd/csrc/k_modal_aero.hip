@@ -89,6 +89,46 @@ __device__ __forceinline__ Wght calcwghts(cptr_t g, const double *s_g, const dou
     return w;
 }
 
+// The same interval through the slice's bucket lookup (colphys_common.h, AERO_LUTB): the count of grid points <= x is
+// cnt[b] + (x >= gin[b]) with b cut from the high word of x.  Identical ix1 / ix2 / t to the scan above for every
+// x that is not a NaN.  s_gin / s_cnt: this grid's lookup arrays in LDS; base / shift: wave-uniform.
+template <int N>
+__device__ __forceinline__ Wght calcwghts_lut(const double *s_gin, const unsigned char *s_cnt, int base, int shift,
+                                              const double *s_g, const double *s_rdx, double x)
+{
+    const int hi = max(__double2hiint(x), 0);
+    const int b = min(max((hi - base) >> shift, 0), AERO_LUTB - 1);
+    const double gin = s_gin[b];
+    int cnt = s_cnt[b];
+    cnt += (x >= gin) ? 1 : 0;
+    const int ix1 = max(cnt, 1), ix2 = min(ix1 + 1, N);
+    const double x1 = s_g[ix1 - 1], rdx = s_rdx[ix1 - 1];
+    const double t = (x - x1) * rdx;
+    Wght w;
+    w.wt1 = 1.0 - t; w.wt2 = t; w.ix1 = ix1 - 1; w.ix2 = ix2 - 1;
+    return w;
+}
+
+// both weights of a (mode, band) unit.  LUT: through the lookup in the LDS slice; else: the scan against the grid read by
+// scalar loads from the slice's global image (gslice)
+template <int NTAB, bool LUT>
+__device__ __forceinline__ void unit_weights(const double *s_tbl, const double *gslice, double refr, double refi, Wght &wr, Wght &wi)
+{
+    const double *s_refr = s_tbl + NTAB * TBLP, *s_refi = s_refr + NR;
+    const double *s_rdxr = s_refi + NI, *s_rdxi = s_rdxr + NR;
+    if (LUT) {
+        const double *s_lut = s_tbl + aero_lut_offset(NTAB);
+        const unsigned char *s_cnt = reinterpret_cast<const unsigned char *>(s_lut + 2 * AERO_LUTB);
+        ciptr_t par = as_const(reinterpret_cast<const int *>(gslice + aero_lut_offset(NTAB) + 2 * AERO_LUTB + 2 * AERO_LUTB / 8));
+        wr = calcwghts_lut<NR>(s_lut, s_cnt, par[0], par[1], s_refr, s_rdxr, refr);
+        wi = calcwghts_lut<NI>(s_lut + AERO_LUTB, s_cnt + AERO_LUTB, par[2], par[3], s_refi, s_rdxi, refi);
+    } else {
+        cptr_t g_grid = as_const(gslice + NTAB * TBLP);                  // uniform -> scalar loads
+        wr = calcwghts<NR>(g_grid, s_refr, s_rdxr, refr);
+        wi = calcwghts<NI>(g_grid + NR, s_refi, s_rdxi, refi);
+    }
+}
+
 // Bilinear table interpolation (table_interp) fused with the Chebyshev sum that consumes it:
 //     p = 0.5*c(1) + sum_{nc=2..5} cheb(nc)*c(nc)        (modal_aer_opt.F90:870-873, 882-887, 1390-1393)
 // with c(nc) the bilinearly interpolated coefficient.  Both operations are linear, so the Chebyshev sum is taken at
@@ -149,7 +189,7 @@ __device__ __forceinline__ void slice_issue(const double *src, double *s_dst)
     }
 }
 
-template <bool SW>
+template <bool SW, bool LUT>
 __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev A, int ncol, int pver, int bands_per_group,
                                                        colphys_modal_aero_io io)
 {
@@ -213,9 +253,6 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
         for (int jb = 0; jb < nbg; ++jb, ++unit) {                      // :726 / :1343
             const int ib = b0 + jb;
             const double *s_tbl = s_slice0 + cur * SLICE;
-            const double *s_refr = s_tbl + NTAB * TBLP;
-            const double *s_refi = s_refr + NR;
-            const double *s_rdxr = s_refi + NI, *s_rdxi = s_rdxr + NR;
             const size_t gsl = (size_t)m * nb + ib;
             // the next (mode, band) slice starts its way into the other buffer
             if (unit + 1 < nunits) {
@@ -246,9 +283,8 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
                 const bool dv = wetvol > 1.e-40;
                 refr = dv ? qr : cre; refi = dv ? qi : cim;
             }
-            cptr_t g_grid = as_const(slices + gsl * SLICE + NTAB * TBLP);   // uniform -> scalar loads
-            const Wght wr = calcwghts<NR>(g_grid, s_refr, s_rdxr, refr);        // :857-858 / :1383-1384
-            const Wght wi = calcwghts<NI>(g_grid + NR, s_refi, s_rdxi, refi);
+            Wght wr, wi;
+            unit_weights<NTAB, LUT>(s_tbl, slices + gsl * SLICE, refr, refi, wr, wi);   // :857-858 / :1383-1384
 
             if (SW) {
                 double pext = interp_cheb(s_tbl, wr, wi, cheb);         // :860, 870-873
@@ -317,6 +353,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
 // ------------------------------------------------------------------------------------------------------
 constexpr int NMMAX = 4;
 
+template <bool LUT>
 __global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(AeroDev A, int ncol, int pver, colphys_modal_aero_io io)
 {
     constexpr int NTAB = 3;
@@ -393,8 +430,6 @@ __global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(Ae
             if (m < A.nmodes) {
                 const int nspec = nsp[m];
                 const double *s_tbl = s_slice0 + cur * SLICE;
-                const double *s_refr = s_tbl + NTAB * TBLP, *s_refi = s_refr + NR;
-                const double *s_rdxr = s_refi + NI, *s_rdxi = s_rdxr + NR;
                 const size_t gsl = (size_t)m * nb + ib;
                 {   // next slice: (m+1, ib) or (0, ib+1)
                     const int mn = (m + 1 < A.nmodes) ? m + 1 : 0;
@@ -417,9 +452,8 @@ __global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(Ae
                 cre = cre * wetinv[m];
                 cim = cim * wetinv[m];
                 const double refr = cre, refi = fabs(cim);
-                cptr_t g_grid = as_const(slices + gsl * SLICE + NTAB * TBLP);
-                const Wght wr = calcwghts<NR>(g_grid, s_refr, s_rdxr, refr);
-                const Wght wi = calcwghts<NI>(g_grid + NR, s_refi, s_rdxi, refi);
+                Wght wr, wi;
+                unit_weights<NTAB, LUT>(s_tbl, slices + gsl * SLICE, refr, refi, wr, wi);
                 double pext = interp_cheb(s_tbl, wr, wi, cheb[m]);
                 double pabs = interp_cheb(s_tbl + TBLP, wr, wi, cheb[m]);
                 const double pasm = interp_cheb(s_tbl + 2 * TBLP, wr, wi, cheb[m]);
@@ -501,6 +535,7 @@ __device__ __constant__ int diag_slot_field[3 * DIAG_ROUND] = {
     COLPHYS_SWD_COL_AOD0, COLPHYS_SWD_COL_AOD0 + 1, COLPHYS_SWD_COL_AOD0 + 2, COLPHYS_SWD_COL_AOD0 + 3, COLPHYS_SWD_COL_AOD0 + 4,
     COLPHYS_SWD_COL_AOD0 + 5, -1, -1};
 
+template <bool LUT>
 __global__ __launch_bounds__(NT, DIAG_WAVES) void modal_aero_sw_diag_kernel(AeroDev A, int ncol, int pver, int cpb, colphys_modal_aero_io io,
                                                                              double *__restrict__ lev, double *__restrict__ colf)
 {
@@ -557,8 +592,6 @@ __global__ __launch_bounds__(NT, DIAG_WAVES) void modal_aero_sw_diag_kernel(Aero
     for (int m = 0; m < A.nmodes; ++m) {                                // :706
         const int nspec = as_const(A.nspec)[m];
         const double *s_tbl = s_slice0 + cur * SLICE;
-        const double *s_refr = s_tbl + NTAB * TBLP, *s_refi = s_refr + NR;
-        const double *s_rdxr = s_refi + NI, *s_rdxi = s_rdxr + NR;
 
         double v[NSMAX], radsurf, logradsurf, cheb[NC];
         const double dgn = n_dgn, qw = n_qw;
@@ -602,9 +635,8 @@ __global__ __launch_bounds__(NT, DIAG_WAVES) void modal_aero_sw_diag_kernel(Aero
             slice_issue<SLICE>(slices + ((size_t)(m + 1) * nb + ivis) * SLICE, s_slice0 + (cur ^ 1) * SLICE);
             load_mode(m + 1);
         }
-        cptr_t g_grid = as_const(slices + ((size_t)m * nb + ivis) * SLICE + NTAB * TBLP);
-        const Wght wr = calcwghts<NR>(g_grid, s_refr, s_rdxr, refr);    // :857-862
-        const Wght wi = calcwghts<NI>(g_grid + NR, s_refi, s_rdxi, refi);
+        Wght wr, wi;
+        unit_weights<NTAB, LUT>(s_tbl, slices + ((size_t)m * nb + ivis) * SLICE, refr, refi, wr, wi);    // :857-862
         double pext = interp_cheb(s_tbl, wr, wi, cheb);
         double pabs = interp_cheb(s_tbl + TBLP, wr, wi, cheb);
         const double pasm = interp_cheb(s_tbl + 2 * TBLP, wr, wi, cheb);
@@ -777,21 +809,17 @@ static int launch_aero(bool sw, const AeroDev &A, int ncol, int pver, const colp
         // LDS: the slice double buffer + the species volumes of all modes, [sum of nspec][NT] (nspec lives on the device:
         // size for the largest table the engine accepts would waste LDS, so the host mirror of nspec is used)
         const size_t lds_reg = (2 * slice + (size_t)A.nspec_total * NT) * sizeof(double);
+        auto kern = A.lut_ok_sw ? modal_aero_sw_reg_kernel<true> : modal_aero_sw_reg_kernel<false>;
         if (lds_reg > 64 * 1024)
-            hipFuncSetAttribute((const void *)modal_aero_sw_reg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
-        hipLaunchKernelGGL(modal_aero_sw_reg_kernel, g1, dim3(NT), lds_reg, st, A, ncol, pver, io);
+            hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+        hipLaunchKernelGGL(kern, g1, dim3(NT), lds_reg, st, A, ncol, pver, io);
         return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
     }
 #endif
-    if (sw) {
-        if (lds > 64 * 1024)
-            hipFuncSetAttribute((const void *)modal_aero_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(modal_aero_kernel<true>, grid, dim3(NT), lds, st, A, ncol, pver, bpg, io);
-    } else {
-        if (lds > 64 * 1024)
-            hipFuncSetAttribute((const void *)modal_aero_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(modal_aero_kernel<false>, grid, dim3(NT), lds, st, A, ncol, pver, bpg, io);
-    }
+    auto kern = sw ? (A.lut_ok_sw ? modal_aero_kernel<true, true> : modal_aero_kernel<true, false>)
+                   : (A.lut_ok_lw ? modal_aero_kernel<false, true> : modal_aero_kernel<false, false>);
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, A, ncol, pver, bpg, io);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
 
@@ -811,10 +839,10 @@ int launch_modal_aero_sw_diag(const AeroDev &A, int ncol, int pver, const colphy
     const int cpb = std::min(NT / pver, DIAG_CPB);
     const size_t lds = (2 * (size_t)aero_slice_doubles(3) + (size_t)DIAG_NSLOT * DIAG_STRIDE) * sizeof(double);
     if (lds > 160 * 1024) return COLPHYS_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024)
-        hipFuncSetAttribute((const void *)modal_aero_sw_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kern = A.lut_ok_sw ? modal_aero_sw_diag_kernel<true> : modal_aero_sw_diag_kernel<false>;
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const dim3 grid((unsigned)((ncol + cpb - 1) / cpb));
-    hipLaunchKernelGGL(modal_aero_sw_diag_kernel, grid, dim3(NT), lds, st, A, ncol, pver, cpb, io, lev, col);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, A, ncol, pver, cpb, io, lev, col);
     hipLaunchKernelGGL(modal_aero_sw_diag_tau_kernel, grid, dim3(NT), 0, st, A, ncol, pver, cpb, io, lev, col);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
