@@ -673,7 +673,7 @@ int colphys_aero_tables_set(const colphys_aero_tables *tb)
             for (int j = 1; j < n && ok; ++j) ok = bucket(g[j], bs, sh) != bucket(g[j - 1], bs, sh);
             if (!ok) return false;                               // coarser buckets only merge more
             for (int b = 0; b < AERO_LUTB; ++b) {
-                gin[b] = std::numeric_limits<double>::infinity();
+                gin[b] = std::numeric_limits<double>::quiet_NaN();      // empty bucket: x >= NaN is false for every x, +inf included
                 int below = 0;
                 for (int j = 0; j < n; ++j) {
                     const int bj = bucket(g[j], bs, sh);
@@ -774,6 +774,20 @@ static int aero_dev(bool sw, int ncol, int pver, const colphys_modal_aero_io *io
 }
 int colphys_modal_aero_sw_dev(int ncol, int pver, const colphys_modal_aero_io *io, void *stream) { return aero_dev(true, ncol, pver, io, stream); }
 int colphys_modal_aero_lw_dev(int ncol, int pver, const colphys_modal_aero_io *io, void *stream) { return aero_dev(false, ncol, pver, io, stream); }
+
+int colphys_aero_grid_probe_dev(int sw, int mode, int band, int which, int use_lut, int64_t n, const double *x, int32_t *ix1,
+                                int32_t *ix2, double *t, int32_t *lut_available, void *stream)
+{
+    int rc;
+    if ((rc = check_ready())) return rc;
+    if (!g_aero_set) return fail(COLPHYS_ERR_NOTINIT, "colphys_aero_tables_set has not been called");
+    const int nb = sw ? g_A.nswbands : g_A.nlwbands;
+    if (mode < 0 || mode >= g_A.nmodes || band < 0 || band >= nb || which < 0 || which > 1 || n < 0 || (n > 0 && (!x || !ix1 || !ix2 || !t)))
+        return fail(COLPHYS_ERR_ARG, "bad grid probe arguments");
+    if (lut_available) *lut_available = sw ? g_A.lut_ok_sw : g_A.lut_ok_lw;
+    rc = launch_aero_grid_probe(g_A, sw, mode, band, which, use_lut, n, x, ix1, ix2, t, (hipStream_t)stream);
+    return rc ? fail(rc, "grid probe launch failed") : COLPHYS_OK;
+}
 
 int colphys_modal_aero_sw_diag_dev(int ncol, int pver, const colphys_modal_aero_io *io, double *lev, double *col, void *stream)
 {

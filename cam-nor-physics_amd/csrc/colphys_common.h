@@ -65,7 +65,7 @@ constexpr int AERO_TBLP = COLPHYS_PREFI * COLPHYS_PREFR * AERO_NCP;
 // logarithmic across binades and linear inside one, which suits both the linear real-index grids and the geometric
 // imaginary-index grids of the modal optics files -- chosen on the host so that no bucket holds more than one grid point.
 // Then  #{j : g_j <= x} = cnt[b] + (x >= gin[b]),  cnt[b] = grid points in lower buckets, gin[b] = the grid point inside
-// bucket b (+inf if none): one compare instead of one per grid point, and the grid leaves the SGPRs.
+// bucket b (NaN if none: the compare is then false): one compare instead of one per grid point, and the grid leaves the SGPRs.
 // Slice image after the tables and the four grid arrays: gin_r[LUTB], gin_i[LUTB] doubles; cnt_r[LUTB], cnt_i[LUTB]
 // bytes; int32 base_r, shift_r, base_i, shift_i, ok (ok = 0: some bucket would hold two points -> the kernels' linear
 // search is used for the whole table set).
@@ -317,6 +317,8 @@ int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, con
                    const double *winds_v = nullptr);
 int launch_modal_aero_sw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);
 int launch_modal_aero_lw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);
+int launch_aero_grid_probe(const AeroDev &A, int sw, int mode, int band, int which, int use_lut, long long n, const double *x,
+                           int *ix1, int *ix2, double *t, hipStream_t st);
 int launch_modal_aero_sw_diag(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, double *lev, double *col,
                               hipStream_t st);
 int launch_physics_update(int ncol, int pver, double dt, double cpair, double qmin, const double *t_in,

@@ -782,7 +782,36 @@ __global__ __launch_bounds__(NT) void modal_aero_sw_diag_tau_kernel(AeroDev A, i
     }
 }
 
+// Diagnostic: table_interp's interval search of one grid of one slice, by the scan or by the bucket lookup, on arbitrary x
+// (colphys_aero_grid_probe_dev; the tests walk every grid point and its neighbours in floating point through both).
+__global__ void aero_grid_probe_kernel(const double *slice, int ntab, int which, int use_lut, long long n, const double *x,
+                                       int *ix1, int *ix2, double *t)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *g_refr = slice + ntab * TBLP, *g_refi = g_refr + NR, *g_rdxr = g_refi + NI, *g_rdxi = g_rdxr + NR;
+    const double *lut = slice + aero_lut_offset(ntab);
+    const unsigned char *cnt = reinterpret_cast<const unsigned char *>(lut + 2 * AERO_LUTB);
+    const int *par = reinterpret_cast<const int *>(lut + 2 * AERO_LUTB + 2 * AERO_LUTB / 8);
+    Wght w;
+    if (which == 0)
+        w = use_lut ? calcwghts_lut<NR>(lut, cnt, par[0], par[1], g_refr, g_rdxr, x[i]) : calcwghts<NR>(as_const(g_refr), g_refr, g_rdxr, x[i]);
+    else
+        w = use_lut ? calcwghts_lut<NI>(lut + AERO_LUTB, cnt + AERO_LUTB, par[2], par[3], g_refi, g_rdxi, x[i])
+                    : calcwghts<NI>(as_const(g_refi), g_refi, g_rdxi, x[i]);
+    ix1[i] = w.ix1 + 1; ix2[i] = w.ix2 + 1; t[i] = w.wt2;
+}
+
 }  // namespace
+
+int launch_aero_grid_probe(const AeroDev &A, int sw, int mode, int band, int which, int use_lut, long long n, const double *x,
+                           int *ix1, int *ix2, double *t, hipStream_t st)
+{
+    const int ntab = sw ? 3 : 1, nb = sw ? A.nswbands : A.nlwbands;
+    const double *slice = (sw ? A.slices_sw : A.slices_lw) + ((size_t)mode * nb + band) * aero_slice_doubles(ntab);
+    if (n > 0) hipLaunchKernelGGL(aero_grid_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slice, ntab, which, use_lut, n, x, ix1, ix2, t);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}
 
 static int launch_aero(bool sw, const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st)
 {

@@ -69,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "colphys_aero_tables_set",
     "colphys_modal_aero_sw_dev", "colphys_modal_aero_lw_dev",
     "colphys_modal_aero_sw_chunks", "colphys_modal_aero_lw_chunks",
-    "colphys_modal_aero_sw_diag_dev", "colphys_modal_aero_sw_diag_chunks",
+    "colphys_modal_aero_sw_diag_dev", "colphys_modal_aero_sw_diag_chunks", "colphys_aero_grid_probe_dev",
     "colphys_profile_enable", "colphys_profile_reset", "colphys_profile_get", "colphys_math_probe_dev",
 ]
 
@@ -373,6 +373,18 @@ class ColumnPhysics:
         io.tauxar = _p(out["tauxar"]); io.status = _p(out["status"], abi.PI)
         self._check(self.lib.colphys_modal_aero_lw_dev(C.c_int(n), C.c_int(pver), C.byref(io), self._stream()))
         return out
+
+    def aero_grid_probe(self, sw: bool, mode: int, band: int, which: int, use_lut: bool, x):
+        """table_interp's interval search of one grid (which: 0 real, 1 imaginary index) on device values x ->
+        (ix1, ix2, t, lut_available); diagnostic (include/colphys.h colphys_aero_grid_probe_dev)"""
+        x = self._f64(x)
+        n = x.numel()
+        ix1 = self.empty(n, dtype=self.torch.int32); ix2 = self.empty(n, dtype=self.torch.int32); t = self.empty(n)
+        avail = C.c_int32(0)
+        self._check(self.lib.colphys_aero_grid_probe_dev(C.c_int(int(sw)), C.c_int(mode), C.c_int(band), C.c_int(which),
+                                                         C.c_int(int(use_lut)), C.c_int64(n), _p(x), _p(ix1, abi.PI), _p(ix2, abi.PI),
+                                                         _p(t), C.byref(avail), self._stream()))
+        return ix1, ix2, t, bool(avail.value)
 
     # ---- measurement ---------------------------------------------------------------------------------
     def profile_enable(self, on: bool):

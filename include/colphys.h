@@ -494,6 +494,13 @@ int colphys_profile_get(int kernel, double *avg_ms, int64_t *launches);
 #define COLPHYS_PROBE_SVP   2
 int colphys_math_probe_dev(int kind, int64_t n, const double *x, double *y, void *stream);
 
+/* Diagnostic: table_interp's interval search (table_interp_calcwghts; modal_aer_opt.F90:857-858, 1383-1384) of one grid of
+ * one (mode, band) table set -- which = 0 the real-index grid, 1 the imaginary-index grid -- evaluated on device values x:
+ * 1-based ix1, ix2 and the weight t of ix2.  use_lut = 0: the scan over the grid points (the reference's loop);
+ * 1: the bucket lookup the optics kernels use when *lut_available is 1 (only then meaningful).  Both must agree. */
+int colphys_aero_grid_probe_dev(int sw, int mode, int band, int which, int use_lut, int64_t n, const double *x, int32_t *ix1,
+                                int32_t *ix2, double *t, int32_t *lut_available, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -430,6 +430,86 @@ def test_modal_aero_sw_diagnostics_identities_at_full_size():
     assert (col[4] <= col[0] * (1 + 1e-14)).all()                 # sum dopaer*palb <= sum dopaer
 
 
+def _table_interp_intervals(g, x):
+    """table_interp_calcwghts (oracle/stubs/l0_arithmetic.F90, restated in oracle/colphys_oracle_aero.c calcwghts): first grid
+    point above x, extrapolation below the grid, clamp above it"""
+    n = len(g)
+    ii = np.searchsorted(g, x, side="right") + 1                 # first 1-based j with x < g_j
+    ix1 = np.maximum(ii - 1, 1); ix2 = np.minimum(ix1 + 1, n)
+    dx = g[ix2 - 1] - g[ix1 - 1]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        t = np.where(np.abs(dx) > 1.0e-20, (x - g[ix1 - 1]) / np.where(dx == 0, 1.0, dx), 0.0)
+    return ix1.astype(np.int32), ix2.astype(np.int32), t
+
+
+@pytest.mark.parametrize("sw,mode,band", [(True, 0, 0), (True, 3, 13), (False, 1, 7)])
+def test_table_interp_interval_search_scan_vs_lookup(sw, mode, band):
+    """The optics kernels find table_interp's interval through a bucket lookup cut from the high word of x
+    (colphys_common.h AERO_LUTB).  Walk every grid point, its floating-point neighbours, the ends, zero, negative, denormal,
+    huge and infinite arguments through the lookup and through the reference's scan: same interval, bit-identical weight."""
+    eng = engine(cases.default_params(32))
+    props = synth.make_aero_props(17)
+    eng.aero_tables_set(props, synth.PHYSCONST)
+    rng = np.random.default_rng(99)
+    for which, key in ((0, "refrtab"), (1, "refitab")):
+        g = np.asarray(props[key + ("sw" if sw else "lw")][mode, band], dtype=np.float64)
+        xs = [g]
+        for steps in (1, 2, 3):
+            up, dn = g.copy(), g.copy()
+            for _ in range(steps):
+                up, dn = np.nextafter(up, np.inf), np.nextafter(dn, -np.inf)
+            xs += [up, dn]
+        xs += [0.5 * (g[1:] + g[:-1]), np.array([0.0, -0.0, -1.0, -1.0e-300, 5.0e-324, 1.0e-310, 1.0e-30, 1.0e300, np.inf]),
+               rng.uniform(-0.2, 3.0, 4000), 10.0 ** rng.uniform(-12, 2, 4000), g[-1] * (1 + 10.0 ** rng.uniform(-16, 0, 500)),
+               g[1] * (1 - 10.0 ** rng.uniform(-16, 0, 500))]
+        x = np.concatenate(xs)
+        a1, a2, at, avail = eng.aero_grid_probe(sw, mode, band, which, False, eng.dev(x))
+        b1, b2, bt, _ = eng.aero_grid_probe(sw, mode, band, which, True, eng.dev(x))
+        assert avail, "the synthetic tables (linear real grid, geometric imaginary grid from 0) must admit the lookup"
+        a1, a2, at, b1, b2, bt = (v.cpu().numpy() for v in (a1, a2, at, b1, b2, bt))
+        assert np.array_equal(a1, b1) and np.array_equal(a2, b2), np.argwhere(a1 != b1)[:5]
+        assert np.array_equal(at, bt, equal_nan=True)                # x = inf: inf * 0 in both
+        r1, r2, rt = _table_interp_intervals(g, x)
+        assert np.array_equal(a1, r1) and np.array_equal(a2, r2)
+        fin = np.isfinite(x)
+        assert np.allclose(at[fin], rt[fin], rtol=1e-14, atol=1e-300)
+
+
+def test_modal_aero_tables_without_lookup_fall_back_to_the_scan(monkeypatch):
+    """two real-index grid points one part in 1e12 apart share every bucket: no lookup for the SW tables, the kernels scan
+    the grid; the LW tables keep theirs.  Then COLPHYS_AERO_NO_LUT forces the scan everywhere: bit-identical results."""
+    from c_oracle import COracle
+    pver, ncol = 32, 300
+    params = cases.default_params(pver)
+    eng = engine(params)
+    co = COracle(params)
+    props = synth.make_aero_props(21)
+    st = synth.make_state(ncol, pver, 21)
+    aer = synth.make_aero_state(ncol, pver, props, 21)
+    d = eng.dev
+    a = (d(st["pdeldry"]), d(aer["specmmr"]), d(aer["dgnumwet"]), d(aer["qaerwat"]))
+    eng.aero_tables_set(props, synth.PHYSCONST)
+    sw_lut, lw_lut = to_np(eng.modal_aero_sw(*a)), to_np(eng.modal_aero_lw(*a))
+    assert eng.aero_grid_probe(True, 0, 0, 0, True, d(np.ones(1)))[3] and eng.aero_grid_probe(False, 0, 0, 0, True, d(np.ones(1)))[3]
+    monkeypatch.setenv("COLPHYS_AERO_NO_LUT", "1")
+    eng.aero_tables_set(props, synth.PHYSCONST)
+    assert not eng.aero_grid_probe(True, 0, 0, 0, False, d(np.ones(1)))[3]
+    sw_scan, lw_scan = to_np(eng.modal_aero_sw(*a)), to_np(eng.modal_aero_lw(*a))
+    for k in ("tauxar", "wa", "ga", "fa"):
+        assert np.array_equal(sw_lut[k], sw_scan[k]), k
+    assert np.array_equal(lw_lut["tauxar"], lw_scan["tauxar"])
+    monkeypatch.delenv("COLPHYS_AERO_NO_LUT")
+    props["refrtabsw"] = props["refrtabsw"].copy()
+    props["refrtabsw"][1, 5, 3] = props["refrtabsw"][1, 5, 2] * (1.0 + 1.0e-12)
+    eng.aero_tables_set(props, synth.PHYSCONST)
+    co.aero_tables_set(props, synth.PHYSCONST)
+    assert not eng.aero_grid_probe(True, 0, 0, 0, False, d(np.ones(1)))[3]
+    assert eng.aero_grid_probe(False, 0, 0, 0, False, d(np.ones(1)))[3]
+    sw, sw_ref = to_np(eng.modal_aero_sw(*a)), co.modal_aero_sw(st, aer)
+    for k in ("tauxar", "wa", "ga", "fa"):
+        assert_close("modal_aero_sw." + k, sw[k], sw_ref[k])
+
+
 def test_modal_aero_edge_branches_vs_c_oracle():
     """the optics' side branches: negative aerosol water (:841-844), particles beyond the size table in both directions
     (:1559-1561 clamp, :875 large-particle extinction), refractive indices outside the table grid (table_interp
