@@ -69,6 +69,39 @@ __device__ __forceinline__ cptr_t as_const(const double *p) { return (cptr_t)(co
 typedef const __attribute__((address_space(4))) int *ciptr_t;
 __device__ __forceinline__ ciptr_t as_const(const int *p) { return (ciptr_t)(const void *)p; }
 
+// Volume mixing of the species' refractive indices (:767 / :1360) for a mode of exactly NS species, straight-line: the
+// NS scalar loads of (re, im) go out as one batch and the FMAs follow without branches.  (A loop over l < nspec with a
+// uniform branch per species made every load a round trip of its own and left phi copies behind every branch.)
+// V(l): the species' volume of this lane.
+template <int NS, class V>
+__device__ __forceinline__ void mix_ns(V vol, cptr_t ri, size_t stride, double &cre, double &cim)
+{
+    double re[NS], im[NS];
+#pragma unroll
+    for (int l = 0; l < NS; ++l) { re[l] = ri[l * stride]; im[l] = ri[l * stride + 1]; }
+#pragma unroll
+    for (int l = 0; l < NS; ++l) {
+        const double vl = vol(l);
+        cre = cre + vl * re[l];
+        cim = cim + vl * im[l];
+    }
+}
+template <class V>
+__device__ __forceinline__ void mix(int nspec, V vol, cptr_t ri, size_t stride, double &cre, double &cim)
+{
+    switch (nspec) {                                    // wave-uniform
+    case 1: mix_ns<1>(vol, ri, stride, cre, cim); break;
+    case 2: mix_ns<2>(vol, ri, stride, cre, cim); break;
+    case 3: mix_ns<3>(vol, ri, stride, cre, cim); break;
+    case 4: mix_ns<4>(vol, ri, stride, cre, cim); break;
+    case 5: mix_ns<5>(vol, ri, stride, cre, cim); break;
+    case 6: mix_ns<6>(vol, ri, stride, cre, cim); break;
+    case 7: mix_ns<7>(vol, ri, stride, cre, cim); break;
+    case 8: mix_ns<8>(vol, ri, stride, cre, cim); break;
+    default: break;
+    }
+}
+
 // calcwghts of table_interp: first grid point above x (the reference's loop with exit), extrapolating below the
 // grid and clamping above it.  g: the grid through a wave-uniform global pointer (scalar loads -> SGPR operands);
 // s_g / s_rdx: the same grid and the reciprocal widths 1/(g[j+1]-g[j]) of its intervals in LDS (packed with the
@@ -263,13 +296,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
             // volume-mixed complex refractive index :767, 846-850 / :1360, 1375-1378
             cptr_t ri = as_const((SW ? A.specrefindex_sw : A.specrefindex_lw) + ((size_t)m * A.nspec_max * nb + ib) * 2);
             double cre = 0.0, cim = 0.0;
-#pragma unroll
-            for (int l = 0; l < NSMAX; ++l) {
-                if (l < nspec) {
-                    cre = cre + vol[l] * ri[(size_t)l * nb * 2];
-                    cim = cim + vol[l] * ri[(size_t)l * nb * 2 + 1];
-                }
-            }
+            mix(nspec, [&](int l) { return vol[l]; }, ri, (size_t)nb * 2, cre, cim);
             cptr_t crefw = as_const((SW ? A.crefwsw : A.crefwlw) + ib * 2);
             cre = cre + watervol * crefw[0];
             cim = cim + watervol * crefw[1];
@@ -438,14 +465,8 @@ __global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(Ae
                 }
                 cptr_t ri = as_const(A.specrefindex_sw + ((size_t)m * A.nspec_max * nb + ib) * 2);
                 double cre = 0.0, cim = 0.0;
-#pragma unroll
-                for (int l = 0; l < NSMAX; ++l) {
-                    if (l < nspec) {
-                        const double vl = s_vol[(voff[m] + l) * NT];
-                        cre = cre + vl * ri[(size_t)l * nb * 2];
-                        cim = cim + vl * ri[(size_t)l * nb * 2 + 1];
-                    }
-                }
+                const double *s_vm = s_vol + voff[m] * NT;
+                mix(nspec, [&](int l) { return s_vm[l * NT]; }, ri, (size_t)nb * 2, cre, cim);
                 cptr_t crefw = as_const(A.crefwsw + ib * 2);
                 cre = cre + watervol[m] * crefw[0];
                 cim = cim + watervol[m] * crefw[1];
