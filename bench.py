@@ -51,8 +51,8 @@ def substep_bytes(L):
 
 PMC_KERNEL = {"geopotential_t": "geopotential_kernel", "zm_trigger": "zm_trigger_kernel", "zm_plume1": "zm_plume1_kernel",
               "zm_ascent2": "zm_ascent2_kernel", "zm_plume2": "zm_plume2_kernel",
-              "zm_conv_evap": "zm_conv_evap_kernel", "momtran": "momtran_wave_kernel", "modal_aero_sw": "modal_aero_sw_reg_kernel",
-              "modal_aero_lw": "modal_aero_kernel<false>"}
+              "zm_conv_evap": "zm_conv_evap_kernel", "momtran": "momtran_wave_kernel", "modal_aero_sw": "modal_aero_reg_kernel<true, true>",
+              "modal_aero_lw": "modal_aero_kernel<false, true>"}
 
 
 def pmc_of(kernel):
@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--no-aero", action="store_true", help="configs[1]: ZM only (zm_convr + zm_conv_evap + momtran)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying a captured HIP graph")
+    ap.add_argument("--lw-kernel", choices=["auto", "bands-outer", "grouped"], default="grouped",
+                    help="kernel family of modal_aero_lw (colphys_aero_kernel_select); the substep is fastest with `grouped`")
     ap.add_argument("--serial", action="store_true", help="all kernels on one stream (no ZM || optics overlap)")
     args = ap.parse_args()
 
@@ -196,6 +198,11 @@ def main():
     # The optics kernels share no data with the ZM chain, so they go on a second HIP stream and fill the SIMDs
     # the latency-bound ZM kernels leave idle (760 column groups, then ~80, on 1 024 SIMDs); --serial disables it.
     side = torch.cuda.Stream(priority=0) if (with_aero and not args.serial) else None
+    if with_aero:
+        # beside the ZM chain the grouped LW kernel measures 0.6 % faster per substep than the bands-outer one, which is 15 %
+        # faster alone (include/colphys.h colphys_aero_kernel_select; A/B in DESIGN.md section 4).  The same kernels run in
+        # the --serial passes the profiles are taken from.
+        eng.aero_kernel_select("auto", args.lw_kernel)
 
     def aero():
         eng.modal_aero_sw(S["pdeldry"], A["specmmr"], A["dgnumwet"], A["qaerwat"], out=sw_out)

@@ -775,6 +775,16 @@ static int aero_dev(bool sw, int ncol, int pver, const colphys_modal_aero_io *io
 int colphys_modal_aero_sw_dev(int ncol, int pver, const colphys_modal_aero_io *io, void *stream) { return aero_dev(true, ncol, pver, io, stream); }
 int colphys_modal_aero_lw_dev(int ncol, int pver, const colphys_modal_aero_io *io, void *stream) { return aero_dev(false, ncol, pver, io, stream); }
 
+int colphys_aero_kernel_select(int sw_kind, int lw_kind)
+{
+    if (sw_kind < COLPHYS_AERO_KERNEL_AUTO || sw_kind > COLPHYS_AERO_KERNEL_GROUPED || lw_kind < COLPHYS_AERO_KERNEL_AUTO ||
+        lw_kind > COLPHYS_AERO_KERNEL_GROUPED)
+        return fail(COLPHYS_ERR_ARG, "unknown aerosol-optics kernel kind");
+    std::lock_guard<std::mutex> lk(g_mu);
+    aero_kernel_select(sw_kind, lw_kind);
+    return COLPHYS_OK;
+}
+
 int colphys_aero_grid_probe_dev(int sw, int mode, int band, int which, int use_lut, int64_t n, const double *x, int32_t *ix1,
                                 int32_t *ix2, double *t, int32_t *lut_available, void *stream)
 {

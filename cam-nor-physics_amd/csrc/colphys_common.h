@@ -317,6 +317,7 @@ int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, con
                    const double *winds_v = nullptr);
 int launch_modal_aero_sw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);
 int launch_modal_aero_lw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);
+void aero_kernel_select(int sw_kind, int lw_kind);
 int launch_aero_grid_probe(const AeroDev &A, int sw, int mode, int band, int which, int use_lut, long long n, const double *x,
                            int *ix1, int *ix2, double *t, hipStream_t st);
 int launch_modal_aero_sw_diag(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, double *lev, double *col,

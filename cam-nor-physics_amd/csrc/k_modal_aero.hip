@@ -22,7 +22,7 @@
 //                accumulators [band][NOUT][256 cells] in LDS (lane-contiguous, conflict-free); grid.y = band group:
 //                the bands are split so that accumulators + slices fit AERO_LDS_CAP_KB and three blocks share a CU
 //                (the per-(cell, mode) size / volume prologue is recomputed per group).
-// modal_aero_sw_reg_kernel (SW): bands outer, modes inner, see there.
+// modal_aero_reg_kernel (up to four modes): bands outer, modes inner, see there.
 // Both add a band's modes in the reference's order.
 // table_interp semantics: oracle/stubs/l0_arithmetic.F90 (parity-unpinned seam).
 #include "colphys_common.h"
@@ -34,6 +34,9 @@
 #endif
 #ifndef AERO_SW_WAVES
 #define AERO_SW_WAVES 3                    // bands-outer SW kernel: waves per SIMD the register budget is set for
+#endif
+#ifndef AERO_LW_WAVES
+#define AERO_LW_WAVES 4                    // bands-outer LW kernel
 #endif
 #ifndef AERO_PRIO
 #define AERO_PRIO 0                       // issue priority of the optics waves (the ZM chain runs at COLPHYS_CHAIN_PRIO)
@@ -380,17 +383,17 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
 // ------------------------------------------------------------------------------------------------------
 constexpr int NMMAX = 4;
 
-template <bool LUT>
-__global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(AeroDev A, int ncol, int pver, colphys_modal_aero_io io)
+template <bool SW, bool LUT>
+__global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_aero_reg_kernel(AeroDev A, int ncol, int pver, colphys_modal_aero_io io)
 {
-    constexpr int NTAB = 3;
+    constexpr int NTAB = SW ? 3 : 1;
     constexpr int SLICE = aero_slice_doubles(NTAB);
     __builtin_amdgcn_s_setprio(AERO_PRIO);
     extern __shared__ double smem[];
     double *s_slice0 = smem;                           // two slices (double buffer)
     double *s_vol = smem + 2 * SLICE + threadIdx.x;    // species volumes [slot][NT], slot = species counted through the modes
 
-    const int nb = A.nswbands;
+    const int nb = SW ? A.nswbands : A.nlwbands;
     const size_t L = (size_t)pver, F = (size_t)ncol * L, LP = L + 1;
     const size_t cell = (size_t)blockIdx.x * NT + threadIdx.x;
     const bool live = cell < F;
@@ -399,11 +402,11 @@ __global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(Ae
     const int k = (int)(cc - (size_t)col * L) + 1;
     const bool active = live && k >= A.top_lev;
     const double rh2odens = 1.0 / A.rhoh2o;
-    const double *slices = A.slices_sw;
+    const double *slices = SW ? A.slices_sw : A.slices_lw;
 
     slice_issue<SLICE>(slices, s_slice0);              // (mode 0, band 0)
 
-    const double mass = io.pdeldry[cc] * A.rga;        // :644
+    const double mass = io.pdeldry[cc] * A.rga;        // :644 / :1300
     int bad = 0;
 
     double cheb[NMMAX][NC], watervol[NMMAX], wetvol[NMMAX], wetinv[NMMAX], radsurf[NMMAX];
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(Ae
             wetvol[m] = watervol[m] + dryvol;
             if (watervol[m] < 0.0) { watervol[m] = 0.0; wetvol[m] = dryvol; }
             small[m] = logradsurf <= A.xrmax;
-            wetinv[m] = 1.0 / fmax(wetvol[m], 1.e-60);
+            wetinv[m] = 1.0 / (SW ? fmax(wetvol[m], 1.e-60) : wetvol[m]);       // :848 / :1377
         }
     }
     __syncthreads();
@@ -463,45 +466,62 @@ __global__ __launch_bounds__(NT, AERO_SW_WAVES) void modal_aero_sw_reg_kernel(Ae
                     const int ibn = (m + 1 < A.nmodes) ? ib : ib + 1;
                     if (ibn < nb) slice_issue<SLICE>(slices + ((size_t)mn * nb + ibn) * SLICE, s_slice0 + (cur ^ 1) * SLICE);
                 }
-                cptr_t ri = as_const(A.specrefindex_sw + ((size_t)m * A.nspec_max * nb + ib) * 2);
+                cptr_t ri = as_const((SW ? A.specrefindex_sw : A.specrefindex_lw) + ((size_t)m * A.nspec_max * nb + ib) * 2);
                 double cre = 0.0, cim = 0.0;
                 const double *s_vm = s_vol + voff[m] * NT;
                 mix(nspec, [&](int l) { return s_vm[l * NT]; }, ri, (size_t)nb * 2, cre, cim);
-                cptr_t crefw = as_const(A.crefwsw + ib * 2);
+                cptr_t crefw = as_const((SW ? A.crefwsw : A.crefwlw) + ib * 2);
                 cre = cre + watervol[m] * crefw[0];
                 cim = cim + watervol[m] * crefw[1];
-                cre = cre * wetinv[m];
-                cim = cim * wetinv[m];
-                const double refr = cre, refi = fabs(cim);
+                double refr, refi;
+                if (SW) {
+                    refr = cre * wetinv[m]; refi = fabs(cim * wetinv[m]);
+                } else {
+                    const bool dv = wetvol[m] > 1.e-40;                 // :1376
+                    refr = dv ? cre * wetinv[m] : cre; refi = dv ? cim * wetinv[m] : cim;
+                }
                 Wght wr, wi;
                 unit_weights<NTAB, LUT>(s_tbl, slices + gsl * SLICE, refr, refi, wr, wi);
-                double pext = interp_cheb(s_tbl, wr, wi, cheb[m]);
-                double pabs = interp_cheb(s_tbl + TBLP, wr, wi, cheb[m]);
-                const double pasm = interp_cheb(s_tbl + 2 * TBLP, wr, wi, cheb[m]);
-                const double pe = exp(pext);
-                pext = small[m] ? pe : 1.5 / (radsurf[m] * A.rhoh2o);
-                pext = pext * wetvol[m] * A.rhoh2o;
-                pabs = pabs * wetvol[m] * A.rhoh2o;
-                pabs = fmax(0.0, pabs);
-                pabs = fmin(pext, pabs);
-                const double palb = 1.0 - pabs / fmax(pext, 1.e-40);
-                const double dopaer = pext * mass;
-                if (dopaer <= -1.e-10 || dopaer >= 30.0) bad = 1;
-                a0 = a0 + dopaer;
-                a1 = a1 + dopaer * palb;
-                a2 = a2 + dopaer * palb * pasm;
-                a3 = a3 + dopaer * palb * pasm * pasm;
+                if (SW) {
+                    double pext = interp_cheb(s_tbl, wr, wi, cheb[m]);
+                    double pabs = interp_cheb(s_tbl + TBLP, wr, wi, cheb[m]);
+                    const double pasm = interp_cheb(s_tbl + 2 * TBLP, wr, wi, cheb[m]);
+                    const double pe = exp(pext);
+                    pext = small[m] ? pe : 1.5 / (radsurf[m] * A.rhoh2o);
+                    pext = pext * wetvol[m] * A.rhoh2o;
+                    pabs = pabs * wetvol[m] * A.rhoh2o;
+                    pabs = fmax(0.0, pabs);
+                    pabs = fmin(pext, pabs);
+                    const double palb = 1.0 - pabs / fmax(pext, 1.e-40);
+                    const double dopaer = pext * mass;
+                    if (dopaer <= -1.e-10 || dopaer >= 30.0) bad = 1;
+                    a0 = a0 + dopaer;
+                    a1 = a1 + dopaer * palb;
+                    a2 = a2 + dopaer * palb * pasm;
+                    a3 = a3 + dopaer * palb * pasm * pasm;
+                } else {
+                    double pabs = interp_cheb(s_tbl, wr, wi, cheb[m]);  // :1386, 1390-1393
+                    pabs = pabs * wetvol[m] * A.rhoh2o;
+                    pabs = fmax(0.0, pabs);
+                    const double dopaer = pabs * mass;
+                    if (dopaer <= -1.e-10 || dopaer >= 20.0) bad = 1;   // :1402
+                    a0 = a0 + dopaer;                                   // :1441
+                }
                 __syncthreads();
                 cur ^= 1;
             }
         }
         if (live) {
-            const size_t o = ((size_t)col * nb + ib) * LP + k;
-            io.tauxar[o] = active ? a0 : 0.0;
-            io.wa[o] = active ? a1 : 0.0;
-            io.ga[o] = active ? a2 : 0.0;
-            io.fa[o] = active ? a3 : 0.0;
-            if (k == 1) { io.tauxar[o - 1] = 0.0; io.wa[o - 1] = 0.925; io.ga[o - 1] = 0.850; io.fa[o - 1] = 0.7225; }
+            if (SW) {
+                const size_t o = ((size_t)col * nb + ib) * LP + k;
+                io.tauxar[o] = active ? a0 : 0.0;
+                io.wa[o] = active ? a1 : 0.0;
+                io.ga[o] = active ? a2 : 0.0;
+                io.fa[o] = active ? a3 : 0.0;
+                if (k == 1) { io.tauxar[o - 1] = 0.0; io.wa[o - 1] = 0.925; io.ga[o - 1] = 0.850; io.fa[o - 1] = 0.7225; }
+            } else {
+                io.tauxar[((size_t)col * nb + ib) * L + (k - 1)] = active ? a0 : 0.0;
+            }
         }
     }
     if (live && bad && active) atomicOr(io.status + col, COLPHYS_STATUS_DOPAER_RANGE);
@@ -834,6 +854,10 @@ int launch_aero_grid_probe(const AeroDev &A, int sw, int mode, int band, int whi
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
 
+// kernel family per routine (colphys_aero_kernel_select): 0 automatic = bands-outer when the mode count allows
+static int g_aero_kind[2] = {COLPHYS_AERO_KERNEL_AUTO, COLPHYS_AERO_KERNEL_AUTO};      // [0] SW, [1] LW
+void aero_kernel_select(int sw_kind, int lw_kind) { g_aero_kind[0] = sw_kind; g_aero_kind[1] = lw_kind; }
+
 static int launch_aero(bool sw, const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st)
 {
     if (A.nspec_max > NSMAX) return COLPHYS_ERR_UNSUPPORTED;
@@ -853,13 +877,15 @@ static int launch_aero(bool sw, const AeroDev &A, int ncol, int pver, const colp
     const dim3 grid((unsigned)((cells + NT - 1) / NT), (unsigned)ngroups);
     if (hipMemsetAsync(io.status, 0, sizeof(int32_t) * ncol, st) != hipSuccess) return COLPHYS_ERR_HIP;
 #ifndef AERO_SW_GROUPED
-    const char *force_grouped = getenv("COLPHYS_SW_GROUPED");      // tests: the fallback for more than NMMAX modes
-    if (sw && A.nmodes <= NMMAX && !(force_grouped && atoi(force_grouped))) {
+    const char *force_grouped = getenv(sw ? "COLPHYS_SW_GROUPED" : "COLPHYS_LW_GROUPED");      // tests: the kernel that serves more than NMMAX modes
+    const bool reg = !(force_grouped && atoi(force_grouped)) && g_aero_kind[sw ? 0 : 1] != COLPHYS_AERO_KERNEL_GROUPED;
+    if (A.nmodes <= NMMAX && reg) {
         const dim3 g1((unsigned)((cells + NT - 1) / NT));
         // LDS: the slice double buffer + the species volumes of all modes, [sum of nspec][NT] (nspec lives on the device:
         // size for the largest table the engine accepts would waste LDS, so the host mirror of nspec is used)
         const size_t lds_reg = (2 * slice + (size_t)A.nspec_total * NT) * sizeof(double);
-        auto kern = A.lut_ok_sw ? modal_aero_sw_reg_kernel<true> : modal_aero_sw_reg_kernel<false>;
+        auto kern = sw ? (A.lut_ok_sw ? modal_aero_reg_kernel<true, true> : modal_aero_reg_kernel<true, false>)
+                       : (A.lut_ok_lw ? modal_aero_reg_kernel<false, true> : modal_aero_reg_kernel<false, false>);
         if (lds_reg > 64 * 1024)
             hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
         hipLaunchKernelGGL(kern, g1, dim3(NT), lds_reg, st, A, ncol, pver, io);

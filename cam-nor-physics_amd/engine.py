@@ -69,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "colphys_aero_tables_set",
     "colphys_modal_aero_sw_dev", "colphys_modal_aero_lw_dev",
     "colphys_modal_aero_sw_chunks", "colphys_modal_aero_lw_chunks",
-    "colphys_modal_aero_sw_diag_dev", "colphys_modal_aero_sw_diag_chunks", "colphys_aero_grid_probe_dev",
+    "colphys_modal_aero_sw_diag_dev", "colphys_modal_aero_sw_diag_chunks", "colphys_aero_grid_probe_dev", "colphys_aero_kernel_select",
     "colphys_profile_enable", "colphys_profile_reset", "colphys_profile_get", "colphys_math_probe_dev",
 ]
 
@@ -373,6 +373,12 @@ class ColumnPhysics:
         io.tauxar = _p(out["tauxar"]); io.status = _p(out["status"], abi.PI)
         self._check(self.lib.colphys_modal_aero_lw_dev(C.c_int(n), C.c_int(pver), C.byref(io), self._stream()))
         return out
+
+    AERO_KERNEL = {"auto": 0, "bands-outer": 1, "grouped": 2}
+
+    def aero_kernel_select(self, sw: str = "auto", lw: str = "auto"):
+        """kernel family of modal_aero_sw / modal_aero_lw (include/colphys.h colphys_aero_kernel_select)"""
+        self._check(self.lib.colphys_aero_kernel_select(C.c_int(self.AERO_KERNEL[sw]), C.c_int(self.AERO_KERNEL[lw])))
 
     def aero_grid_probe(self, sw: bool, mode: int, band: int, which: int, use_lut: bool, x):
         """table_interp's interval search of one grid (which: 0 real, 1 imaginary index) on device values x ->

@@ -367,6 +367,17 @@ typedef struct colphys_modal_aero_io {
     int32_t *status;                      /* [ncol] */
 } colphys_modal_aero_io;
 
+/* Which of the two kernel families serves modal_aero_sw / modal_aero_lw (same results to rounding; both are tested against
+ * the same goldens).  AUTO = BANDS_OUTER when the tables have at most four modes, else GROUPED.  BANDS_OUTER keeps every
+ * mode's size / volume state of a cell and walks the bands once: fastest alone (the call pattern of the radiation driver).
+ * GROUPED walks modes outer / a band group inner with LDS accumulators: for LW it is 15 % slower alone but leaves the CUs'
+ * LDS and wave slots freer, which measures 0.6 % faster when the optics run BESIDE the ZM chain on a second stream
+ * (bench.py's substep). */
+#define COLPHYS_AERO_KERNEL_AUTO        0
+#define COLPHYS_AERO_KERNEL_BANDS_OUTER 1
+#define COLPHYS_AERO_KERNEL_GROUPED     2
+int colphys_aero_kernel_select(int sw_kind, int lw_kind);
+
 int colphys_modal_aero_sw_dev(int ncol, int pver, const colphys_modal_aero_io *io, void *stream);
 int colphys_modal_aero_lw_dev(int ncol, int pver, const colphys_modal_aero_io *io, void *stream);
 int colphys_modal_aero_sw_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io);

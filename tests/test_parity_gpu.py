@@ -234,22 +234,25 @@ def test_convtran_many_tracers_vs_c_oracle(ncnst, pver, ncol):
             assert np.array_equal(got2[m], got[m]), m               # gathered dpdry argument == pdeldry gathered on the fly
 
 
-@pytest.mark.parametrize("sw_kernel", ["bands-outer", "grouped"])
+@pytest.mark.parametrize("family", ["bands-outer", "grouped"])
 @pytest.mark.parametrize("name", cases.AERO_GOLDEN)
-def test_modal_aero_vs_reference_golden(name, sw_kernel, monkeypatch):
-    """both SW kernels: bands-outer (up to four modes) and the grouped one that serves more modes (forced here)"""
-    if sw_kernel == "grouped":
-        monkeypatch.setenv("COLPHYS_SW_GROUPED", "1")
+def test_modal_aero_vs_reference_golden(name, family):
+    """both kernel families, SW and LW (colphys_aero_kernel_select): bands-outer (up to four modes) and the grouped one that
+    also serves more modes"""
     g = cases.load_golden(name)
     pver = g["in_t"].shape[1]
     eng = engine(cases.default_params(pver))
     eng.aero_tables_set(synth.make_aero_props(int(g["seed"])), synth.PHYSCONST)
     d = eng.dev
     a = (d(g["in_pdeldry"]), d(g["in_specmmr"]), d(g["in_dgnumwet"]), d(g["in_qaerwat"]))
-    sw = to_np(eng.modal_aero_sw(*a))
+    eng.aero_kernel_select(family, family)
+    try:
+        sw = to_np(eng.modal_aero_sw(*a))
+        lw = to_np(eng.modal_aero_lw(*a))
+    finally:
+        eng.aero_kernel_select("auto", "auto")
     for k in ("tauxar", "wa", "ga", "fa"):
         assert_close("modal_aero_sw." + k, sw[k], g["sw_" + k])
-    lw = to_np(eng.modal_aero_lw(*a))
     assert_close("modal_aero_lw.tauxar", lw["tauxar"], g["lw_tauxar"])
     assert not sw["status"].any() and not lw["status"].any()
     assert (sw["tauxar"] >= 0).all() and (lw["tauxar"] >= 0).all()
