@@ -326,14 +326,14 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
                 pabs = pabs * wetvol * A.rhoh2o;
                 pabs = fmax(0.0, pabs);
                 pabs = fmin(pext, pabs);
-                const double palb = 1.0 - pabs / fmax(pext, 1.e-40);
                 const double dopaer = pext * mass;
+                const double dw = (pext - pabs) * mass;                 // dopaer*palb without the quotient (see the bands-outer kernel)
                 if (dopaer <= -1.e-10 || dopaer >= 30.0) bad = 1;       // :997
                 double *acc = s_acc + (size_t)jb * 4 * NT + threadIdx.x;
                 acc[0] = acc[0] + dopaer;                               // :1032-1037
-                acc[NT] = acc[NT] + dopaer * palb;
-                acc[2 * NT] = acc[2 * NT] + dopaer * palb * pasm;
-                acc[3 * NT] = acc[3 * NT] + dopaer * palb * pasm * pasm;
+                acc[NT] = acc[NT] + dw;
+                acc[2 * NT] = acc[2 * NT] + dw * pasm;
+                acc[3 * NT] = acc[3 * NT] + dw * pasm * pasm;
             } else {
                 double pabs = interp_cheb(s_tbl, wr, wi, cheb);         // :1386, 1390-1393
                 pabs = pabs * wetvol * A.rhoh2o;
@@ -492,13 +492,16 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
                     pabs = pabs * wetvol[m] * A.rhoh2o;
                     pabs = fmax(0.0, pabs);
                     pabs = fmin(pext, pabs);
-                    const double palb = 1.0 - pabs / fmax(pext, 1.e-40);
+                    // dopaer*palb = pext*mass*(1 - pabs/max(pext, 1e-40)) (:892-894, 1034) without the quotient: mass*(pext - pabs).
+                    // Equal to rounding for pext > 1e-40 (0 <= pabs <= pext, so neither form cancels worse than the other);
+                    // below that both are < 1e-40 * mass.  A division sequence less per (band, mode) unit.
                     const double dopaer = pext * mass;
+                    const double dw = (pext - pabs) * mass;
                     if (dopaer <= -1.e-10 || dopaer >= 30.0) bad = 1;
                     a0 = a0 + dopaer;
-                    a1 = a1 + dopaer * palb;
-                    a2 = a2 + dopaer * palb * pasm;
-                    a3 = a3 + dopaer * palb * pasm * pasm;
+                    a1 = a1 + dw;
+                    a2 = a2 + dw * pasm;
+                    a3 = a3 + dw * pasm * pasm;
                 } else {
                     double pabs = interp_cheb(s_tbl, wr, wi, cheb[m]);  // :1386, 1390-1393
                     pabs = pabs * wetvol[m] * A.rhoh2o;
