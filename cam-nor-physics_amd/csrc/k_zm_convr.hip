@@ -681,8 +681,13 @@ __global__ __launch_bounds__(WAVE) void zm_trigger_fused_kernel(ZmDev P, int nco
 //   * the genuine recurrences / searches / running sums run in the reference's order, redundantly on all
 //     lanes (uniform control flow: in SIMT that costs exactly what one lane would), reading and writing LDS.
 // A barrier separates a PAR phase from whatever reads its neighbours' levels.  Same arithmetic, same order.
+// PSTEP = lanes per column: 64, or 32 when pver <= 32 -- then a wave carries TWO columns, lanes 0..31 the first and 32..63
+// the second, each half with its own LDS profiles (otherwise half the lanes of every PAR loop idle and twice the waves run
+// the serial loops).  Nothing else changes: a lane belongs to a column and does what that column's control flow says; where
+// the two columns of a wave disagree (loop bounds, `eps0 > 0`, the break of :3690) the wave runs both sides under EXEC
+// masks.  A block is one wave, so SYNC() inside such a branch is safe: LDS operations of a wave complete in order.
 // ------------------------------------------------------------------------------------------------------
-#define PAR(k, lo, hi) for (int k = (lo) + lane; k <= (hi); k += WAVE)
+#define PAR(k, lo, hi) for (int k = (lo) + lane; k <= (hi); k += PSTEP)      // PSTEP: lanes per column (template parameter in scope)
 #define SYNC() __syncthreads()
 
 constexpr int PLUME_NARR = 49;
@@ -705,6 +710,7 @@ struct PlumeLds {
 struct PlumeIdx { int jt, jlcl, j0, jd; };
 
 // column inputs -> LDS (:825-860, 926-940) and the interface values shat / qhat (:1007-1027)
+template <int PSTEP>
 __device__ void plume_load(const ZmDev &P, const ColIn &c, const PlumeLds &A, int lane)
 {
     const int pver = c.pver, msg = c.msg;
@@ -734,7 +740,7 @@ __device__ void plume_load(const ZmDev &P, const ColIn &c, const PlumeLds &A, in
 // ENTRAINMENT_ONLY: the first call of the reference (:1032) is made for one thing, the entrainment profile eu that
 // sets the second ascent's rate (:1046-1078); everything cldprp computes after eu is final is overwritten by the second
 // call, so the first pass stops there.
-template <bool ENTRAINMENT_ONLY>
+template <bool ENTRAINMENT_ONLY, int PSTEP>
 __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, int jb, int lel, double landfrac, int lane,
                          PlumeIdx &o)
 {
@@ -1116,6 +1122,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
 }
 
 // closure :4028-4260: the per-level integrand one level per lane, the sum in the reference's order
+template <int PSTEP>
 __device__ double closure_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, double *s_dboy, double dsubcld, double cape,
                             double tl, int lcl, int lel, int jt, int mx, int lane)
 {
@@ -1173,22 +1180,25 @@ __device__ double closure_w(const ZmDev &P, int pver, int msg, const PlumeLds &A
 // ------------------------------------------------------------------------------------------------------
 // Kernel 2a: first cloud-ensemble pass -> the test parcel's entrainment rate for the second ascent (:1032-1078)
 // ------------------------------------------------------------------------------------------------------
+template <int CPWV>
 __global__ __launch_bounds__(WAVE) void zm_plume1_kernel(ZmDev P, int ncol, int pver, colphys_zm_convr_io io, ZmWorkspace ws)
 {
+    constexpr int PSTEP = WAVE / CPWV;          // lanes per column
     CHAIN_PRIO();
     extern __shared__ double smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (PSTEP - 1), half = CPWV == 1 ? 0 : threadIdx.x / PSTEP;
     const int msg = P.limcnv - 1;
     const int LD = pver + 2;
     PlumeLds A;
-    A.carve(smem, LD);
+    A.carve(smem + (size_t)half * (PLUME_NARR + 2) * LD, LD);
     const int count = *ws.count;
-    for (int b = blockIdx.x; b < count; b += gridDim.x) {      // persistent waves over the triggered list
-    const int col = ws.list[b];
+    for (int b0 = blockIdx.x * CPWV; b0 < count; b0 += gridDim.x * CPWV) {      // persistent waves over the triggered list
+    const bool valid = b0 + half < count;
+    const int col = ws.list[valid ? b0 + half : b0];           // an idle half shadows the wave's first column
     const ColIn c = make_colin(P, io, col, pver);
-    plume_load(P, c, A, lane);
+    plume_load<PSTEP>(P, c, A, lane);
     PlumeIdx ix;
-    cldprp_w<true>(P, pver, msg, A, ws.mx1[col], ws.lel1[col], c.landfrac, lane, ix);        // :1032
+    cldprp_w<true, PSTEP>(P, pver, msg, A, ws.mx1[col], ws.lel1[col], c.landfrac, lane, ix);        // :1032
     double dmpdz = -1.0;                                                                     // :1046-1078
     {
         double hk = 0.0, dmmx = 0.0, dmsm = 0.0;
@@ -1206,7 +1216,7 @@ __global__ __launch_bounds__(WAVE) void zm_plume1_kernel(ZmDev P, int ncol, int 
             dmpdz = dmsm * orgc + dmmx * (1.0 - orgc);
         }
     }
-    if (lane == 0) ws.dmpdz2[col] = dmpdz;
+    if (lane == 0 && valid) ws.dmpdz2[col] = dmpdz;
     SYNC();
     }
 }
@@ -1246,24 +1256,34 @@ __global__ __launch_bounds__(2 * WAVE, CHAIN_WAVES_PER_SIMD) void zm_ascent2_ker
 // ------------------------------------------------------------------------------------------------------
 // Kernel 2c: second ensemble pass, closure, tendencies, precipitation integrals of the re-triggered columns
 // ------------------------------------------------------------------------------------------------------
+template <int CPWV>
 __global__ __launch_bounds__(WAVE, CHAIN_WAVES_PER_SIMD) void zm_plume2_kernel(ZmDev P, int ncol, int pver, double delt, colphys_zm_convr_io io,
                                                         ZmWorkspace ws)
 {
+    constexpr int PSTEP = WAVE / CPWV;          // lanes per column
     CHAIN_PRIO();
     extern __shared__ double smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (PSTEP - 1), half = CPWV == 1 ? 0 : threadIdx.x / PSTEP;
     const int msg = P.limcnv - 1;
     const int LD = pver + 2;
     const size_t L = (size_t)pver, LP = (size_t)pver + 1;
     PlumeLds A;
-    A.carve(smem, LD);
-    double *s_w1 = smem + (size_t)PLUME_NARR * LD, *s_w2 = s_w1 + LD;       // dboydt / dqdt, dl
+    double *base = smem + (size_t)half * (PLUME_NARR + 2) * LD;
+    A.carve(base, LD);
+    double *s_w1 = base + (size_t)PLUME_NARR * LD, *s_w2 = s_w1 + LD;       // dboydt / dqdt, dl
     const int count = *ws.count;
-    for (int b = blockIdx.x; b < count; b += gridDim.x) {      // persistent waves over the triggered list
-    const int col = ws.list[b];
-    if (!ws.retrig[col]) continue;
+    for (int b0 = blockIdx.x * CPWV; b0 < count; b0 += gridDim.x * CPWV) {      // persistent waves over the triggered list
+    int col = ws.list[b0 + half < count ? b0 + half : b0];
+    const bool valid = b0 + half < count && ws.retrig[col];
+    if (CPWV == 1) {
+        if (!valid) continue;
+    } else {
+        if (!__any(valid)) continue;
+        const int other = __shfl_xor(col, PSTEP);              // a half without a column of its own shadows the other half's
+        if (!valid) col = other;
+    }
     const ColIn c = make_colin(P, io, col, pver);
-    plume_load(P, c, A, lane);
+    plume_load<PSTEP>(P, c, A, lane);
     PAR(k, 1, pver) { A.tp[k] = ws.tp2[col * L + k - 1]; A.qstp[k] = ws.qstp2[col * L + k - 1]; }
 
     const int maxg = ws.mx2[col], lelg = ws.lel2[col], lcl = ws.lcl2[col];                   // :1156-1174
@@ -1273,7 +1293,7 @@ __global__ __launch_bounds__(WAVE, CHAIN_WAVES_PER_SIMD) void zm_plume2_kernel(Z
         if (k >= maxg) dsubcld = dsubcld + A.dp[k];
 
     PlumeIdx ix;
-    cldprp_w<false>(P, pver, msg, A, maxg, lelg, c.landfrac, lane, ix);                      // :1216
+    cldprp_w<false, PSTEP>(P, pver, msg, A, maxg, lelg, c.landfrac, lane, ix);               // :1216
     const int jt = ix.jt, mx = maxg;
 
     PAR(k, msg + 1, pver) {                                                                  // :1252-1262
@@ -1283,7 +1303,7 @@ __global__ __launch_bounds__(WAVE, CHAIN_WAVES_PER_SIMD) void zm_plume2_kernel(Z
         A.evp[k] = A.evp[k] * dzk / dpk;
     }
     SYNC();
-    double mb = closure_w(P, pver, msg, A, s_w1, dsubcld, cape, tl, lcl, lelg, jt, mx, lane);                // :1273
+    double mb = closure_w<PSTEP>(P, pver, msg, A, s_w1, dsubcld, cape, tl, lcl, lelg, jt, mx, lane);         // :1273
     double mumax = 0;                                                                        // :1285-1300
     for (int k = msg + 2; k <= pver; ++k) mumax = fmax(mumax, A.mu[k] / A.dp[k]);
     if (mumax > 0.0) mb = fmin(mb, 0.5 / (delt * mumax));
@@ -1324,22 +1344,26 @@ __global__ __launch_bounds__(WAVE, CHAIN_WAVES_PER_SIMD) void zm_plume2_kernel(Z
         }
         if (k >= mx) { dsdt = dsdt_mx; dq = dqdt_mx; }                                       // :4404-4416
         dqdt[k] = dq; dlg[k] = dl;
-        o_qtnd[k] = dq;                                                                      // :1495-1511
-        o_cme[k] = A.cmeg[k];
-        o_rprd[k] = A.rprd[k];
-        o_zdu[k] = A.du[k];
-        o_mcon[k] = A.mc[k];
-        o_heat[k] = dsdt * P.cpres;
-        o_dlf[k] = dl;
-        o_pflx[k] = A.pflx[k];
-        o_ql[k] = A.ql[k];
-        o_eurt[k] = -dmpdz;                                                                  // :1233-1237
+        if (valid) {
+            o_qtnd[k] = dq;                                                                  // :1495-1511
+            o_cme[k] = A.cmeg[k];
+            o_rprd[k] = A.rprd[k];
+            o_zdu[k] = A.du[k];
+            o_mcon[k] = A.mc[k];
+            o_heat[k] = dsdt * P.cpres;
+            o_dlf[k] = dl;
+            o_pflx[k] = A.pflx[k];
+            o_ql[k] = A.ql[k];
+            o_eurt[k] = -dmpdz;                                                              // :1233-1237
+        }
     }
     // full-layout plume profiles; zm_gather_kernel compacts them per chunk
     PAR(k, 1, pver) {
         const size_t g = col * L + k - 1;
-        ws.mu_f[g] = A.mu[k]; ws.md_f[g] = A.md[k]; ws.du_f[g] = A.du[k]; ws.eu_f[g] = A.eu[k]; ws.ed_f[g] = A.ed[k];
-        ws.dp_f[g] = A.dp[k];
+        if (valid) {
+            ws.mu_f[g] = A.mu[k]; ws.md_f[g] = A.md[k]; ws.du_f[g] = A.du[k]; ws.eu_f[g] = A.eu[k]; ws.ed_f[g] = A.ed[k];
+            ws.dp_f[g] = A.dp[k];
+        }
     }
     SYNC();
     double prec = 0.0, rliq = 0.0;
@@ -1353,7 +1377,7 @@ __global__ __launch_bounds__(WAVE, CHAIN_WAVES_PER_SIMD) void zm_plume2_kernel(Z
         const double dlfk = (k >= msg + 1) ? dlg[k] : 0.0;
         rliq = rliq + (dlfk + 0.0) * c.dpp[k] / P.gravit;
     }
-    if (lane == 0) {
+    if (lane == 0 && valid) {
         io.jctop[col] = jt;                                                                  // :1616-1620
         io.jcbot[col] = maxg;
         o_pflx[pver + 1] = A.pflx[pver + 1];
@@ -1497,9 +1521,17 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
         hipLaunchKernelGGL(zm_trigger_fused_kernel, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, io, ws);
     }
     if (ev) { hipEventRecord(ev[1], st); hipEventRecord(ev[2], st); }
-    const size_t lds_w = (size_t)(PLUME_NARR + 2) * (pver + 2) * sizeof(double);
+    // plume kernels: two columns per wave when a column's levels fit half a wave AND the listed columns outnumber the
+    // persistent waves several times over.  A pair of columns takes as long as its slower member plus what the two
+    // disagree on, so it pays only as throughput: 777 602 columns 16.75 -> 16.03 ms (plume2 3.59 -> 3.23), 48 602 columns
+    // -- one or two columns per wave anyway, the time is one column's serial chain -- 2.31 -> 2.37 ms per substep.
+    // (COLPHYS_PLUME_CPW=1|2: tests / A-B)
+    int cpwv = (pver <= WAVE / 2 && ncol >= 150000) ? 2 : 1;
+    if (const char *e = getenv("COLPHYS_PLUME_CPW")) cpwv = (atoi(e) == 2 && pver <= WAVE / 2) ? 2 : 1;
+    const size_t lds_w = (size_t)cpwv * (PLUME_NARR + 2) * (pver + 2) * sizeof(double);
     const int nper = ncol < 256 * 12 ? ncol : 256 * 12;       // persistent: ~12 waves per CU fit in LDS at L32
-    hipLaunchKernelGGL(zm_plume1_kernel, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, io, ws);
+    if (cpwv == 2) hipLaunchKernelGGL(zm_plume1_kernel<2>, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, io, ws);
+    else hipLaunchKernelGGL(zm_plume1_kernel<1>, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, io, ws);
     if (ev) { hipEventRecord(ev[3], st); hipEventRecord(ev[4], st); }
     if (lpc_asc == 2) {
         if (lds2 > 64 * 1024) hipFuncSetAttribute((const void *)zm_ascent2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -1509,7 +1541,8 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
         hipLaunchKernelGGL(zm_ascent2_kernel<1>, dim3(nblk), dim3(2 * WAVE), lds2, st, P, ncol, pver, io, ws);
     }
     if (ev) { hipEventRecord(ev[5], st); hipEventRecord(ev[6], st); }
-    hipLaunchKernelGGL(zm_plume2_kernel, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, delt, io, ws);
+    if (cpwv == 2) hipLaunchKernelGGL(zm_plume2_kernel<2>, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, delt, io, ws);
+    else hipLaunchKernelGGL(zm_plume2_kernel<1>, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, delt, io, ws);
     ZmTendDiag dg{};
     if (diag) dg = *diag;
     hipLaunchKernelGGL(zm_gather_kernel, dim3(nchunks), dim3(WAVE), 0, st, ncol, pver, pcols, io, ws, dg);

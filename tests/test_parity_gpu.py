@@ -59,13 +59,17 @@ def check_zm(o, ref, ncol, pcols=cases.PCOLS):
 # ---------------------------------------------------------------------------------------------------
 # (a) golden fixtures = outputs of the reference Fortran
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("trig_mode", ["auto", "fused"])
+@pytest.mark.parametrize("trig_mode", ["auto", "fused", "plume-pairs"])
 @pytest.mark.parametrize("name", cases.ZM_GOLDEN)
 def test_zm_convr_vs_reference_golden(name, trig_mode, monkeypatch):
     """both mappings of the first ascent: wave pairs (what these column counts select) and the single-wave kernel
-    that takes over when the column groups fill the SIMDs (forced here through COLPHYS_TRIG_MODE)"""
+    that takes over when the column groups fill the SIMDs (forced here through COLPHYS_TRIG_MODE); and the plume kernels with
+    two columns per wave, which large column counts at up to 32 levels select (forced through COLPHYS_PLUME_CPW; L70 keeps
+    one column per wave whatever the setting)"""
     if trig_mode == "fused":
         monkeypatch.setenv("COLPHYS_TRIG_MODE", "2")
+    if trig_mode == "plume-pairs":
+        monkeypatch.setenv("COLPHYS_PLUME_CPW", "2")
     g = cases.load_golden(name)
     eng = engine(cases.golden_params(g))
     o = run_zm(eng, cases.zm_args_from_golden(g))
@@ -546,7 +550,7 @@ def test_modal_aero_edge_branches_vs_c_oracle():
 # ---------------------------------------------------------------------------------------------------
 # (c) properties at BASELINE.json's full size
 # ---------------------------------------------------------------------------------------------------
-def test_full_size_column_independence_and_gather():
+def test_full_size_column_independence_and_gather(monkeypatch):
     """48 602 columns x L32: permuting the columns permutes the per-column results bit for bit; changing the
     chunk width changes only the gathered layout; the gathered layout is a faithful ascending compaction."""
     ncol, pver = 48602, 32
@@ -570,6 +574,13 @@ def test_full_size_column_independence_and_gather():
     o48 = run_zm(eng, args, pcols=48)
     for k in full:
         assert np.array_equal(o48[k], o16[k]), f"{k} depends on pcols"
+    # two columns per wave in the plume kernels (what 150 000 columns and more select): which column shares a wave with
+    # which follows the order the trigger's atomics listed them in, and must not matter
+    monkeypatch.setenv("COLPHYS_PLUME_CPW", "2")
+    o2 = run_zm(eng, args, pcols=16)
+    monkeypatch.delenv("COLPHYS_PLUME_CPW")
+    for k in full + ("mu", "md", "du", "eu", "ed", "dp", "dsubcld", "jt", "maxg", "ideep", "lengath"):
+        assert np.array_equal(o2[k], o16[k]), f"{k} depends on the plume kernels' columns per wave"
     # gathered layout: ideep ascending per chunk, rows equal the full-layout values they came from
     for pcols, o in ((16, o16), (48, o48)):
         m = gathered_mask(o["lengath"], ncol, pcols)
