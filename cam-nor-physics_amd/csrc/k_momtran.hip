@@ -115,11 +115,13 @@ __global__ __launch_bounds__(NT) void momtran_wave_kernel(ZmDev P, int ncol, int
             // operator precedence of the reference kept as is (:2554)
             if (s_md[k] < -mbsth) cond[k] = (-s_ed[km1] * cn[km1] * s_dp[km1]) - pgd[km1] * s_dp[km1] / s_md[k];
         }
+#pragma unroll SCAN_UNROLL
         for (int kk = pver - 1; kk >= 1; --kk) {                                 // :2563-2575
             const double mupdudp = s_mu[kk] + s_du[kk] * s_dp[kk];
             if (mupdudp > mbsth)
                 conu[kk] = (s_mu[kk + 1] * conu[kk + 1] + s_eu[kk] * cn[kk] * s_dp[kk] + pgu[kk] * s_dp[kk]) / mupdudp;
         }
+#pragma unroll SCAN_UNROLL
         for (int k = 3; k <= pver; ++k) {                                        // :2579-2589
             const int km1 = k - 1;
             if (s_md[k] < -mbsth)

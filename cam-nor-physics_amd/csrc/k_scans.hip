@@ -118,6 +118,7 @@ __global__ __launch_bounds__(GNT) void geopotential_kernel(int ncol, int pver, i
     if (c < nc) {
         double zi_kp1 = 0.0;                                   // :207-209
         sZI[c * ldp + pver] = 0.0;
+#pragma unroll SCAN_UNROLL
         for (int k = pver - 1; k >= 0; --k) {
             sZM[c * ldp + k] = zi_kp1 + sZM[c * ldp + k];
             zi_kp1 = zi_kp1 + sZI[c * ldp + k];
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(GNT) void geopotential_dse_kernel(int ncol, int pve
     if (c < nc) {
         double zi_kp1 = 0.0;                                   // :81-83
         sZI[c * ldp + pver] = 0.0;
+#pragma unroll SCAN_UNROLL
         for (int k = pver - 1; k >= 0; --k) {
             const double tv = (sA[c * ldp + k] - gravit * zi_kp1) / sD[c * ldp + k];
             const double rt = sR[c * ldp + k] * tv;
@@ -313,6 +315,7 @@ __global__ __launch_bounds__(ENT) void zm_conv_evap_kernel(ZmDev P, const double
         double evpvint = 0.0, flxprec = 0.0, flxsnow = 0.0;
         sFP[c * ldp] = 0.0;                                                      // :1812-1813
         sFS[c * ldp] = 0.0;
+#pragma unroll SCAN_UNROLL
         for (int k = 0; k < pver; ++k) {
             const double kfac = sT[c * ld + k], pdel = sPD[c * ld + k], prdprec = sPR[c * ld + k], fs = sCL[c * ld + k];
             const bool warm = fs < 0.0;
@@ -487,6 +490,7 @@ __global__ __launch_bounds__(64) void convtran_wave_kernel(int ncol, int pver, i
                 // two levels ahead: q(kk-1), q(kk-2) and fracis(kk-1), fracis(kk-2) are in flight while level kk computes
                 double c_n1 = qm[max(1, pver - 1)], c_n2 = qm[max(1, pver - 2)];
                 double f_n1 = fr[max(1, pver - 1)], f_n2 = fr[max(1, pver - 2)];
+#pragma unroll SCAN_UNROLL
                 for (int kk = pver; kk >= 1; --kk) {
                     const double c_km1 = c_n1;                                   // q(max(1, kk-1))
                     c_n1 = c_n2;
@@ -524,6 +528,7 @@ __global__ __launch_bounds__(64) void convtran_wave_kernel(int ncol, int pver, i
                 double c_n1 = qm[min(pver, 2)], c_n2 = qm[min(pver, 3)];
                 double f_k = fr[1], f_n1 = fr[min(pver, 2)];
                 double cond_k = s_chat[64];                                      // cond(1) = chat(1)
+#pragma unroll SCAN_UNROLL
                 for (int k = 1; k <= pver; ++k) {
                     const int kp1 = min(pver, k + 1);
                     const double c_kp1 = c_n1;                                   // q(min(pver, k+1))

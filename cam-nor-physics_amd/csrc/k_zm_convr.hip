@@ -691,6 +691,9 @@ __global__ __launch_bounds__(WAVE) void zm_trigger_fused_kernel(ZmDev P, int nco
 #define SYNC() __syncthreads()
 
 constexpr int PLUME_NARR = 49;
+#ifndef SERIAL_UNROLL
+#define SERIAL_UNROLL 4                    // serial level loops of the plume kernels: four iterations of LDS reads in flight (plume2 0.21 -> 0.19 ms)
+#endif
 
 struct PlumeLds {
     double *q, *t, *p, *z, *s, *zf, *shat, *qhat, *dp, *tp, *qstp;
@@ -802,6 +805,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
     o.jlcl = lel;
     hmin = 1.E6;
     o.j0 = pver;
+#pragma unroll SERIAL_UNROLL
     for (int k = msg + 1; k <= pver; ++k) {                                                  // :3395-3402
         const double h = A.hsat[k];
         if (h <= hmin && k >= o.jt && k <= jb) { hmin = h; o.j0 = k; }
@@ -819,6 +823,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
     }
     {                                                                                        // :3430-3442 prefix sums
         double k1p = 0.0, i2p = 0.0, i3p = 0.0, i4p = 0.0;     // values at k+1 (all zero at pver)
+#pragma unroll SERIAL_UNROLL
         for (int k = pver - 1; k >= msg + 1; --k) {
             if (k < jb && k >= o.jt) {
                 const double dzk = A.dz[k];
@@ -837,6 +842,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
         }
     }
     hmin = 1.E6;                                                                             // :3446-3456
+#pragma unroll SERIAL_UNROLL
     for (int k = msg + 1; k <= pver; ++k) {
         const double h = A.hmn[k];
         if (k >= o.j0 && k <= jb && h <= hmin) {
@@ -871,6 +877,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
     if (o.j0 < jb) {                                                                         // :3488-3492
         if (A.f[o.j0] < 1.E-6 && A.f[o.j0 + 1] > A.f[o.j0]) o.j0 = o.j0 + 1;
     }
+#pragma unroll SERIAL_UNROLL
     for (int k = msg + 2; k <= pver; ++k)                                                    // :3493-3499 running max
         if (k >= o.jt && k <= o.j0) A.f[k] = fmax(A.f[k], A.f[k - 1]);
     eps0 = A.f[o.j0];                                                                        // :3500-3503
@@ -908,6 +915,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
     SYNC();
     if (eps0 > 0.0) {                                                                        // :3579-3598
         double hu_kp1 = A.hu[jb], mu_kp1 = A.mu[jb];            // carried in registers down the recurrence
+#pragma unroll SERIAL_UNROLL
         for (int k = jb - 1; k >= lel; --k) {
             const double muk = A.mu[k];
             if (muk < 0.02) {
@@ -927,6 +935,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
     {
         bool doit = true;                                                                    // :3603-3628
         const double hu_jb = A.hu[jb];
+#pragma unroll SERIAL_UNROLL
         for (int k = jb - 2; k >= lel - 1; --k) {
             if (doit && k >= 1) {
                 const double huk = A.hu[k], muk = A.mu[k];
@@ -958,6 +967,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
         A.tu[k] = (A.hu[k] - grav * A.zf[k] - (1.0 + dcol * tmelt) * rl * A.qu[k]) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * A.qu[k]));
     }
     SYNC();
+#pragma unroll SERIAL_UNROLL
     for (int k = pver; k >= msg + 2; --k) {                                                  // :3656-3692
         if (k == jb && eps0 > 0.0) {
             const double quk = A.q[mx];
@@ -1002,6 +1012,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
         }
     }
     SYNC();
+#pragma unroll SERIAL_UNROLL
     for (int k = pver; k >= msg + 2; --k) {                                                  // :3846-3870
         double rp = 0.0;
         const double muk = A.mu[k];
@@ -1050,6 +1061,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
         }
     }
     SYNC();
+#pragma unroll SERIAL_UNROLL
     for (int k = msg + 1; k <= pver; ++k) {                                                  // :3916-3924
         if ((k >= jt && k <= pver) && eps0 > 0.0) {
             const double edkm1 = (A.md[k - 1] - A.md[k]) / A.dz[k - 1];
@@ -1078,6 +1090,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
         A.sd[k] = sdk;
         A.td[k] = sdk - grav / ((1.0 + cpvir * qdk) * cp) * A.zf[k];
     }
+#pragma unroll SERIAL_UNROLL
     for (int k = msg + 2; k <= pver; ++k) {                                                  // :3953-3971
         if (k >= jd && k < jb && eps0 > 0.0) {
             const double qdkp1 = A.qds[k + 1];
@@ -1112,6 +1125,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
     {                                                                                        // :4012-4017 prefix sum
         double pf = 0.0;
         A.pflx[1] = 0.0;
+#pragma unroll SERIAL_UNROLL
         for (int k = 2; k <= pver + 1; ++k) {
             pf = pf + A.rprd[k - 1] * A.dz[k - 1];
             A.pflx[k] = pf;
@@ -1171,6 +1185,7 @@ __device__ double closure_w(const ZmDev &P, int pver, int msg, const PlumeLds &A
     }
     SYNC();
     double dadt = 0.0;                                                                       // :4244-4253
+#pragma unroll SERIAL_UNROLL
     for (int k = lel; k <= mx - 1; ++k) dadt = dadt + s_dboy[k] * (A.zf[k] - A.zf[k + 1]);
     const double dltaa = -1.0 * (cape - P.capelmt);
     if (dadt != 0.0) mb = fmax(dltaa / P.tau / dadt, 0.0);
@@ -1203,6 +1218,7 @@ __global__ __launch_bounds__(WAVE) void zm_plume1_kernel(ZmDev P, int ncol, int 
     {
         double hk = 0.0, dmmx = 0.0, dmsm = 0.0;
         const double orgc = 1.0;
+#pragma unroll SERIAL_UNROLL
         for (int k = pver; k >= msg + 1; --k) {
             const double e = A.eu[k];
             if (e > 0) {
@@ -1289,6 +1305,7 @@ __global__ __launch_bounds__(WAVE, CHAIN_WAVES_PER_SIMD) void zm_plume2_kernel(Z
     const int maxg = ws.mx2[col], lelg = ws.lel2[col], lcl = ws.lcl2[col];                   // :1156-1174
     const double cape = ws.cape2[col], tl = ws.tl2[col], dmpdz = ws.dmpdz2[col];
     double dsubcld = 0.0;
+#pragma unroll SERIAL_UNROLL
     for (int k = msg + 1; k <= pver; ++k)
         if (k >= maxg) dsubcld = dsubcld + A.dp[k];
 
@@ -1305,6 +1322,7 @@ __global__ __launch_bounds__(WAVE, CHAIN_WAVES_PER_SIMD) void zm_plume2_kernel(Z
     SYNC();
     double mb = closure_w<PSTEP>(P, pver, msg, A, s_w1, dsubcld, cape, tl, lcl, lelg, jt, mx, lane);         // :1273
     double mumax = 0;                                                                        // :1285-1300
+#pragma unroll SERIAL_UNROLL
     for (int k = msg + 2; k <= pver; ++k) mumax = fmax(mumax, A.mu[k] / A.dp[k]);
     if (mumax > 0.0) mb = fmin(mb, 0.5 / (delt * mumax));
     else mb = 0.0;
@@ -1367,12 +1385,14 @@ __global__ __launch_bounds__(WAVE, CHAIN_WAVES_PER_SIMD) void zm_plume2_kernel(Z
     }
     SYNC();
     double prec = 0.0, rliq = 0.0;
+#pragma unroll SERIAL_UNROLL
     for (int k = pver; k >= msg + 1; --k) {                                                  // :1629-1633 (dif == 0)
         const double qk = A.q[k], dppk = c.dpp[k];
         const double qnew = qk + 2.0 * delt * dqdt[k];
         prec = prec - dppk * (qnew - qk) - dppk * (dlg[k] + 0.0) * 2.0 * delt;
     }
     prec = P.rgrav * fmax(prec, 0.0) / (2.0 * delt) / 1000.0;                                // :1637
+#pragma unroll SERIAL_UNROLL
     for (int k = 1; k <= pver; ++k) {                                                        // :1642-1649
         const double dlfk = (k >= msg + 1) ? dlg[k] : 0.0;
         rliq = rliq + (dlfk + 0.0) * c.dpp[k] / P.gravit;
