@@ -21,7 +21,7 @@
 #define CHAIN_PRIO() __builtin_amdgcn_s_setprio(COLPHYS_CHAIN_PRIO)
 // serial level loops of the scan kernels (one lane = one column, profiles in LDS): iterations the compiler may keep in flight
 #ifndef SCAN_UNROLL
-#define SCAN_UNROLL 1
+#define SCAN_UNROLL 2
 #endif
 
 // Parameters as the kernels see them: colphys_zm_params plus the values zm_convi derives

@@ -877,9 +877,20 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
     if (o.j0 < jb) {                                                                         // :3488-3492
         if (A.f[o.j0] < 1.E-6 && A.f[o.j0 + 1] > A.f[o.j0]) o.j0 = o.j0 + 1;
     }
+    {
+        double f_c = 0.0;
+        bool carried = false;
 #pragma unroll SERIAL_UNROLL
-    for (int k = msg + 2; k <= pver; ++k)                                                    // :3493-3499 running max
-        if (k >= o.jt && k <= o.j0) A.f[k] = fmax(A.f[k], A.f[k - 1]);
+        for (int k = msg + 2; k <= pver; ++k) {                                              // :3493-3499 running max, carried in a register
+            if (k >= o.jt && k <= o.j0) {
+                const double fk = fmax(A.f[k], carried ? f_c : A.f[k - 1]);
+                A.f[k] = fk;
+                f_c = fk; carried = true;
+            } else {
+                carried = false;
+            }
+        }
+    }
     eps0 = A.f[o.j0];                                                                        // :3500-3503
     const double f_j0 = eps0;
     PAR(k, msg + 1, pver) {                                                                  // :3502-3518
@@ -967,20 +978,28 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
         A.tu[k] = (A.hu[k] - grav * A.zf[k] - (1.0 + dcol * tmelt) * rl * A.qu[k]) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * A.qu[k]));
     }
     SYNC();
+    // su / qu of the level below ride in registers (k = jb sets them, jt < k < jb continues them; never read across a gap)
+    double su_c = 0.0, qu_c = 0.0;
+    bool uc = false;
 #pragma unroll SERIAL_UNROLL
     for (int k = pver; k >= msg + 2; --k) {                                                  // :3656-3692
+        bool wrote = false;
         if (k == jb && eps0 > 0.0) {
             const double quk = A.q[mx];
             A.qu[k] = quk;
             const double tuk = (A.hu[k] - grav * A.zf[k] - (1.0 + dcol * tmelt) * rl * quk) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * quk));
             A.tu[k] = tuk;
-            A.su[k] = (A.hu[k] - (1.0 - dcol * (tuk - tmelt)) * rl * quk) / ((1.0 + cpvir * quk) * cp);
+            const double suk = (A.hu[k] - (1.0 - dcol * (tuk - tmelt)) * rl * quk) / ((1.0 + cpvir * quk) * cp);
+            A.su[k] = suk;
+            su_c = suk; qu_c = quk; wrote = true;
         }
         if ((k > o.jt && k < jb) && eps0 > 0.0) {
             const double muk = A.mu[k], mukp1 = A.mu[k + 1], dzk = A.dz[k], euk = A.eu[k], duk = A.du[k];
-            const double suk = mukp1 / muk * A.su[k + 1] + dzk / muk * (euk - duk) * A.s[k];
-            const double quk = mukp1 / muk * A.qu[k + 1] + dzk / muk * (euk * A.q[k] - duk * A.qst[k]);
+            const double sukp1 = uc ? su_c : A.su[k + 1], qukp1 = uc ? qu_c : A.qu[k + 1];
+            const double suk = mukp1 / muk * sukp1 + dzk / muk * (euk - duk) * A.s[k];
+            const double quk = mukp1 / muk * qukp1 + dzk / muk * (euk * A.q[k] - duk * A.qst[k]);
             A.su[k] = suk; A.qu[k] = quk;
+            su_c = suk; qu_c = quk; wrote = true;
             // 0.85 is a default-REAL literal in the reference (:3680): single precision, then promoted
             const double tuk = suk - grav / ((1.0 + (double)0.85f * quk) * cp) * A.zf[k];
             A.tu[k] = tuk;
@@ -991,6 +1010,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
                 break;                                                                       // :3690
             }
         }
+        uc = wrote;
     }
     SYNC();
     PAR(k, msg + 2, pver) {                                                                  // :3693-3707
@@ -1012,12 +1032,15 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
         }
     }
     SYNC();
+    double ql_c = 0.0;                                    // ql of the level below in a register
+    bool qc = false;
 #pragma unroll SERIAL_UNROLL
     for (int k = pver; k >= msg + 2; --k) {                                                  // :3846-3870
         double rp = 0.0;
         const double muk = A.mu[k];
+        bool wrote = false;
         if (k >= o.jt && k < jb && eps0 > 0.0 && muk >= 0.0) {
-            const double dzk = A.dz[k], duk = A.du[k], cuk = A.cu[k], qlkp1 = A.ql[k + 1];
+            const double dzk = A.dz[k], duk = A.du[k], cuk = A.cu[k], qlkp1 = qc ? ql_c : A.ql[k + 1];
             double qlk;
             if (muk > 0.0) {
                 const double ql1 = 1.0 / muk * (A.mu[k + 1] * qlkp1 - dzk * duk * qlkp1 + dzk * cuk);
@@ -1029,8 +1052,10 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
             totpcp = totpcp + dzk * (cuk - duk * qlkp1);
             rp = c0mask * muk * qlk;
             A.qcde[k] = qlk;
+            ql_c = qlk; wrote = true;
         }
         A.rprd[k] = rp;
+        qc = wrote;
     }
 
     // downdraft :3880-3975
@@ -1061,13 +1086,22 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
         }
     }
     SYNC();
+    {   // hd's recurrence in a register (levels k >= jt are contiguous; k = jt reads hd(jt-1) as stored)
+        double hd_c = 0.0;
+        bool carried = false;
 #pragma unroll SERIAL_UNROLL
-    for (int k = msg + 1; k <= pver; ++k) {                                                  // :3916-3924
-        if ((k >= jt && k <= pver) && eps0 > 0.0) {
-            const double edkm1 = (A.md[k - 1] - A.md[k]) / A.dz[k - 1];
-            A.ed[k - 1] = edkm1;
-            mdt = fmin(A.md[k], -small);
-            A.hd[k] = (A.md[k - 1] * A.hd[k - 1] - A.dz[k - 1] * edkm1 * A.hmn[k - 1]) / mdt;
+        for (int k = msg + 1; k <= pver; ++k) {                                              // :3916-3924
+            if ((k >= jt && k <= pver) && eps0 > 0.0) {
+                const double edkm1 = (A.md[k - 1] - A.md[k]) / A.dz[k - 1];
+                A.ed[k - 1] = edkm1;
+                mdt = fmin(A.md[k], -small);
+                const double hdkm1 = carried ? hd_c : A.hd[k - 1];
+                const double hdk = (A.md[k - 1] * hdkm1 - A.dz[k - 1] * edkm1 * A.hmn[k - 1]) / mdt;
+                A.hd[k] = hdk;
+                hd_c = hdk; carried = true;
+            } else {
+                carried = false;
+            }
         }
     }
     SYNC();
@@ -1090,18 +1124,28 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
         A.sd[k] = sdk;
         A.td[k] = sdk - grav / ((1.0 + cpvir * qdk) * cp) * A.zf[k];
     }
+    {   // the recurrences of qd and sd ride in registers: the levels k in [jd, jb) are contiguous, so what level k reads at k
+        // is what level k-1 stored at (k-1)+1 -- except at k = jd, which reads the values set just above
+        double qd_c = 0.0, sd_c = 0.0;
+        bool carried = false;
 #pragma unroll SERIAL_UNROLL
-    for (int k = msg + 2; k <= pver; ++k) {                                                  // :3953-3971
-        if (k >= jd && k < jb && eps0 > 0.0) {
-            const double qdkp1 = A.qds[k + 1];
-            A.qd[k + 1] = qdkp1;
-            const double edk = A.ed[k], qk = A.q[k], dzk = A.dz[k], mdk = A.md[k], mdkp1 = A.md[k + 1], qdk = A.qd[k];
-            double evpk = -edk * qk + (mdk * qdk - mdkp1 * qdkp1) / dzk;
-            evpk = fmax(evpk, 0.0);
-            A.evp[k] = evpk;
-            mdt = fmin(mdkp1, -small);
-            A.sd[k + 1] = (((1.0 - dcol * (A.td[k] - tmelt)) * rl / ((1.0 + cpvir * qdk) * cp) * evpk - edk * A.s[k]) * dzk + mdk * A.sd[k]) / mdt;
-            totevp = totevp - dzk * edk * qk;
+        for (int k = msg + 2; k <= pver; ++k) {                                              // :3953-3971
+            if (k >= jd && k < jb && eps0 > 0.0) {
+                const double qdkp1 = A.qds[k + 1];
+                A.qd[k + 1] = qdkp1;
+                const double edk = A.ed[k], qk = A.q[k], dzk = A.dz[k], mdk = A.md[k], mdkp1 = A.md[k + 1];
+                const double qdk = carried ? qd_c : A.qd[k], sdk = carried ? sd_c : A.sd[k];
+                double evpk = -edk * qk + (mdk * qdk - mdkp1 * qdkp1) / dzk;
+                evpk = fmax(evpk, 0.0);
+                A.evp[k] = evpk;
+                mdt = fmin(mdkp1, -small);
+                const double sdkp1 = (((1.0 - dcol * (A.td[k] - tmelt)) * rl / ((1.0 + cpvir * qdk) * cp) * evpk - edk * A.s[k]) * dzk + mdk * sdk) / mdt;
+                A.sd[k + 1] = sdkp1;
+                totevp = totevp - dzk * edk * qk;
+                qd_c = qdkp1; sd_c = sdkp1; carried = true;
+            } else {
+                carried = false;
+            }
         }
     }
     totevp = totevp + A.md[jd] * A.qd[jd] - A.md[jb] * A.qd[jb];                             // :3974
