@@ -9,20 +9,22 @@
 //   work item  = one cell; a block is 4 waves = 256 consecutive cells of the [ncol][pver] layout
 //                (coalesced reads of pdeldry / dgnumwet / qaerwat / specmmr);
 //   LDS        = the (mode, band) slice of the coefficient tables -- ext/abs/asm(5,7,10) + the two
-//                refractive-index grids and their reciprocal interval widths -- because each cell gathers
+//                refractive-index grids, their reciprocal interval widths and bucket lookups -- because each cell gathers
 //                4 corners x 5 coefficients x 3 tables per (mode, band) at data-dependent indices; coefficients
 //                padded 5 -> 6 so a corner is three 16-byte LDS reads.  The slices are packed ONCE on the host in
 //                exactly this image (colphys_aero_tables_set), so staging is a straight copy done by the LDS-DMA
 //                path (global_load_lds_dwordx4: no staging registers), DOUBLE-BUFFERED: the next slice is in
 //                flight while the current one is used, one barrier per (mode, band);
-//   unit body  = one (mode, band) step is straight-line code: the grid search of table_interp is a
-//                branch-free scan against the grid held in SGPRs (scalar loads: the grid is wave-uniform);
-//                the first version's per-step LDS read + branch chain was the kernel's latency floor.
-// modal_aero_kernel<SW> (LW, and SW with more than four modes): modes outer, bands inner, the block's band
+//   unit body  = one (mode, band) step: the species mixing dispatched once on the species count to straight-line code,
+//                the grid search of table_interp through the slice's bucket lookup (colphys_common.h AERO_LUTB; a
+//                branch-free scan against the grid in SGPRs where a table admits no lookup), three corner-first
+//                Chebyshev / bilinear interpolations.
+// Two kernel families per routine (colphys_aero_kernel_select):
+// modal_aero_reg_kernel<SW|LW> (up to four modes): bands outer, modes inner, every mode's state kept; see there.
+// modal_aero_kernel<SW|LW> ("grouped"; any mode count): modes outer, bands inner, the block's band
 //                accumulators [band][NOUT][256 cells] in LDS (lane-contiguous, conflict-free); grid.y = band group:
 //                the bands are split so that accumulators + slices fit AERO_LDS_CAP_KB and three blocks share a CU
 //                (the per-(cell, mode) size / volume prologue is recomputed per group).
-// modal_aero_reg_kernel (up to four modes): bands outer, modes inner, see there.
 // Both add a band's modes in the reference's order.
 // table_interp semantics: oracle/stubs/l0_arithmetic.F90 (parity-unpinned seam).
 #include "colphys_common.h"
@@ -373,13 +375,14 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
 
 
 // ------------------------------------------------------------------------------------------------------
-// SW, "bands outer, modes inner" (the default for up to 4 modes; -DAERO_SW_GROUPED selects the grouped kernel above): the
+// "Bands outer, modes inner", SW and LW (the default for up to 4 modes; colphys_aero_kernel_select): the
 // per-(cell, mode) state of ALL modes is computed once and kept -- Chebyshev terms, water / wet volume in registers, the
 // species volumes in a lane-private LDS array [species slot][cell] (packed through the modes: sum of nspec slots) -- the
 // four running sums of one band are four registers, and a band is written out as soon as its last mode has been added
 // (same order of additions per output element as the reference's modes-outer loop).  No LDS accumulators, no band
 // groups, no recomputed prologue: 16 % fewer VALU instructions than five band groups.  With the volumes in registers
-// the kernel needed 247 VGPRs (two waves per SIMD, 1.32 ms); with them in LDS it fits 168 (three waves, 1.24 ms).
+// the SW kernel needed 247 VGPRs (two waves per SIMD, 1.32 ms); with them in LDS it fits 168 (three waves, 1.24 ms; 0.955 ms
+// after the lookup / mixing / division work of round 2).  LW: one table, one running sum, 109 VGPRs, four waves per SIMD.
 // ------------------------------------------------------------------------------------------------------
 constexpr int NMMAX = 4;
 
@@ -879,7 +882,6 @@ static int launch_aero(bool sw, const AeroDev &A, int ncol, int pver, const colp
     const size_t cells = (size_t)ncol * pver;
     const dim3 grid((unsigned)((cells + NT - 1) / NT), (unsigned)ngroups);
     if (hipMemsetAsync(io.status, 0, sizeof(int32_t) * ncol, st) != hipSuccess) return COLPHYS_ERR_HIP;
-#ifndef AERO_SW_GROUPED
     const char *force_grouped = getenv(sw ? "COLPHYS_SW_GROUPED" : "COLPHYS_LW_GROUPED");      // tests: the kernel that serves more than NMMAX modes
     const bool reg = !(force_grouped && atoi(force_grouped)) && g_aero_kind[sw ? 0 : 1] != COLPHYS_AERO_KERNEL_GROUPED;
     if (A.nmodes <= NMMAX && reg) {
@@ -894,7 +896,6 @@ static int launch_aero(bool sw, const AeroDev &A, int ncol, int pver, const colp
         hipLaunchKernelGGL(kern, g1, dim3(NT), lds_reg, st, A, ncol, pver, io);
         return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
     }
-#endif
     auto kern = sw ? (A.lut_ok_sw ? modal_aero_kernel<true, true> : modal_aero_kernel<true, false>)
                    : (A.lut_ok_lw ? modal_aero_kernel<false, true> : modal_aero_kernel<false, false>);
     if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
