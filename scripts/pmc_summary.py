@@ -12,6 +12,7 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = sorted(acc)
 ctrs = sorted({c for n in names for c in acc[n]})
-print("kernel," + ",".join(ctrs))
+w = csv.writer(sys.stdout, lineterminator="\n")      # kernel names carry commas (template arguments): quoted
+w.writerow(["kernel"] + ctrs)
 for n in names:
-    print(n + "," + ",".join(f"{sum(acc[n][c])/len(acc[n][c]):.4g}" if acc[n][c] else "" for c in ctrs))
+    w.writerow([n] + [f"{sum(acc[n][c])/len(acc[n][c]):.4g}" if acc[n][c] else "" for c in ctrs])
