@@ -600,7 +600,7 @@ int colphys_math_probe_dev(int kind, int64_t n, const double *x, double *y, void
 {
     int rc;
     if ((rc = check_ready())) return rc;
-    if (kind < COLPHYS_PROBE_LOG || kind > COLPHYS_PROBE_SVP) return fail(COLPHYS_ERR_ARG, "unknown probe kind");
+    if (kind < COLPHYS_PROBE_LOG || kind > COLPHYS_PROBE_EXP) return fail(COLPHYS_ERR_ARG, "unknown probe kind");
     if (n < 0 || (n > 0 && (!x || !y))) return fail(COLPHYS_ERR_ARG, "bad probe arguments");
     rc = launch_math_probe(kind, n, x, y, (hipStream_t)stream);
     return rc ? fail(rc, "math probe launch failed") : COLPHYS_OK;

@@ -190,6 +190,28 @@ __device__ __forceinline__ double cp_exp10(double x)
     return __builtin_amdgcn_ldexp(p, (int)n);
 }
 
+// exp(x) the same way (OCML's reduction x = n ln2 + u with ln2 in two pieces, the same polynomial in u, ldexp), without
+// OCML's overflow / underflow guards: for |x| < 700.  Used by the optics for the specific extinction exp(sum of Chebyshev
+// terms), whose argument is a logarithm of m2/kg values (|x| < 40).  < 1 ulp.
+__device__ __forceinline__ double cp_exp(double x)
+{
+    const double n = __builtin_rint(x * __longlong_as_double(0x3ff71547652b82feLL));       // log2(e)
+    double u = __builtin_fma(__longlong_as_double(0xbfe62e42fefa39efLL), n, x);            // -ln2 (high part)
+    u = __builtin_fma(__longlong_as_double(0xbc7abc9e3b39803fLL), n, u);                   // -ln2 (low part)
+    double p = __builtin_fma(u, __longlong_as_double(0x3e5ade156a5dcb37LL), __longlong_as_double(0x3e928af3fca7ab0cLL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3ec71dee623fde64LL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3efa01997c89e6b0LL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3f2a01a014761f6eLL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3f56c16c1852b7b0LL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3f81111111122322LL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3fa55555555502a1LL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3fc5555555555511LL));
+    p = __builtin_fma(u, p, __longlong_as_double(0x3fe000000000000bLL));
+    p = __builtin_fma(u, p, 1.0);
+    p = __builtin_fma(u, p, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
 // want_ln ? cp_log(x) : cp_log10(x), bit for bit, from ONE reduction + polynomial: the two lanes of a lane pair
 // (below) evaluate a natural and a decimal logarithm of different arguments in the same instruction stream.
 __device__ __forceinline__ double cp_log_sel(double x, bool want_ln)

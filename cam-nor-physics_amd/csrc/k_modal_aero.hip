@@ -322,7 +322,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
                 double pext = interp_cheb(s_tbl, wr, wi, cheb);         // :860, 870-873
                 double pabs = interp_cheb(s_tbl + TBLP, wr, wi, cheb);  // :861, 882-887
                 const double pasm = interp_cheb(s_tbl + 2 * TBLP, wr, wi, cheb);   // :862
-                const double pe = exp(pext);                            // :869-877
+                const double pe = cp_exp(pext);                            // :869-877
                 pext = small ? pe : 1.5 / (radsurf * A.rhoh2o);         // :875 (particles beyond the table: rare)
                 pext = pext * wetvol * A.rhoh2o;                        // :881-894
                 pabs = pabs * wetvol * A.rhoh2o;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
                     double pext = interp_cheb(s_tbl, wr, wi, cheb[m]);
                     double pabs = interp_cheb(s_tbl + TBLP, wr, wi, cheb[m]);
                     const double pasm = interp_cheb(s_tbl + 2 * TBLP, wr, wi, cheb[m]);
-                    const double pe = exp(pext);
+                    const double pe = cp_exp(pext);
                     pext = small[m] ? pe : 1.5 / (radsurf[m] * A.rhoh2o);
                     pext = pext * wetvol[m] * A.rhoh2o;
                     pabs = pabs * wetvol[m] * A.rhoh2o;
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(NT, DIAG_WAVES) void modal_aero_sw_diag_kernel(Aero
         double pext = interp_cheb(s_tbl, wr, wi, cheb);
         double pabs = interp_cheb(s_tbl + TBLP, wr, wi, cheb);
         const double pasm = interp_cheb(s_tbl + 2 * TBLP, wr, wi, cheb);
-        const double pe = exp(pext);                                    // :869-877
+        const double pe = cp_exp(pext);                                    // :869-877
         if (!small) pext = 1.5 / (radsurf * A.rhoh2o); else pext = pe;
         pext = pext * wetvol * A.rhoh2o;                                // :881-894
         pabs = pabs * wetvol * A.rhoh2o;

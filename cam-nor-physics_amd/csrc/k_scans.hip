@@ -838,7 +838,7 @@ __global__ void math_probe_kernel(int kind, int64_t n, const double *__restrict_
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const double v = x[i];
-        y[i] = kind == COLPHYS_PROBE_LOG ? cp_log(v) : (kind == COLPHYS_PROBE_LOG10 ? cp_log10(v) : svp_water_gg(v));
+        y[i] = kind == COLPHYS_PROBE_LOG ? cp_log(v) : kind == COLPHYS_PROBE_LOG10 ? cp_log10(v) : kind == COLPHYS_PROBE_EXP ? cp_exp(v) : svp_water_gg(v);
     }
 }
 }  // namespace

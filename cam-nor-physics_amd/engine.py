@@ -314,7 +314,7 @@ class ColumnPhysics:
                                                         C.c_double(qmin), *ptrs, self._stream()))
 
     # ---- diagnostic: the device log / log10 / svp_water the kernels use ------------------------------
-    PROBE = {"log": 0, "log10": 1, "svp_water": 2}
+    PROBE = {"log": 0, "log10": 1, "svp_water": 2, "exp": 3}
 
     def math_probe(self, kind: str, x):
         x = self._f64(x)

@@ -499,10 +499,12 @@ int colphys_profile_get(int kernel, double *avg_ms, int64_t *launches);
  *   COLPHYS_PROBE_LOG    y = log(x)      (entropy, zm_conv.F90:5297; CAPE integral :4790)
  *   COLPHYS_PROBE_LOG10  y = log10(x)    (Goff-Gratch svp_water, oracle/stubs/l0_arithmetic.F90)
  *   COLPHYS_PROBE_SVP    y = svp_water(x) [Pa], x = temperature [K]
+ *   COLPHYS_PROBE_EXP    y = exp(x)
  * ------------------------------------------------------------------------------------------------- */
 #define COLPHYS_PROBE_LOG   0
 #define COLPHYS_PROBE_LOG10 1
 #define COLPHYS_PROBE_SVP   2
+#define COLPHYS_PROBE_EXP   3   /* y = exp(x), |x| < 700  (specific extinction of the SW optics, modal_aer_opt.F90:874) */
 int colphys_math_probe_dev(int kind, int64_t n, const double *x, double *y, void *stream);
 
 /* Diagnostic: table_interp's interval search (table_interp_calcwghts; modal_aer_opt.F90:857-858, 1383-1384) of one grid of

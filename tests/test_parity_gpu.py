@@ -803,3 +803,8 @@ def test_device_logarithms_within_one_ulp_class():
     es_ref = 10.0 ** (-7.90298 * (tb / t - 1.0) + 5.02808 * np.log10(tb / t) - 1.3816e-7 * (10.0 ** (11.344 * (1.0 - t / tb)) - 1.0)
                       + 8.1328e-3 * (10.0 ** (-3.49149 * (tb / t - 1.0)) - 1.0) + np.log10(1013.246)) * 100.0
     assert np.max(np.abs(es / es_ref - 1.0)) < 1e-14
+    # cp_exp: the optics' exp without OCML's range guards, over and far beyond the log-extinction range it serves
+    xe = np.concatenate([rng.uniform(-40.0, 40.0, 400000), rng.uniform(-700.0, 700.0, 100000), np.array([0.0, -0.0, 1.0, -1.0, 1e-300])])
+    ye = eng.math_probe("exp", eng.dev(xe)).cpu().numpy()
+    re_ = np.exp(xe)
+    assert (np.abs(ye - re_) / np.spacing(re_)).max() <= 2.0
