@@ -217,12 +217,18 @@ template <int SLICE>
 __device__ __forceinline__ void slice_issue(const double *src, double *s_dst)
 {
     constexpr int PIECES = SLICE / 2;                       // 16-byte pieces
-    const int wbase = threadIdx.x & ~(WAVE - 1);
+    // the wave's number as a SCALAR: the "does this wave-instruction exist" test below is then a scalar branch instead of a
+    // v_cmp + saveexec per piece, and the LDS base needs no v_readfirstlane
+    const int wbase = __builtin_amdgcn_readfirstlane(threadIdx.x & ~(WAVE - 1));
+    // per-lane source offset in bytes as an unsigned 32-bit value: uniform base + zero-extended offset selects the
+    // saddr + voffset form of the load (no 64-bit vector add per piece)
+    const unsigned loff = (unsigned)threadIdx.x * 16u;
+    const char *base = (const char *)src;
 #pragma unroll
     for (int j = 0; j * NT < PIECES; ++j) {
         const int e0 = j * NT + wbase;                      // first piece of this wave-instruction (uniform)
         if (e0 < PIECES)
-            __builtin_amdgcn_global_load_lds((const void *)(src + 2 * (size_t)(j * NT + threadIdx.x)),
+            __builtin_amdgcn_global_load_lds((const void *)(base + (size_t)j * NT * 16 + loff),
                                              (__attribute__((address_space(3))) void *)(s_dst + 2 * e0), 16, 0, 0);
     }
 }
