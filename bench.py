@@ -41,12 +41,15 @@ BYTES = {
     "momtran": lambda L: (8 * L + 1) * 8 + 12 + 11 * L * 8,
     "modal_aero_sw": lambda L: 26 * L * 8 + 4 * (L + 1) * 14 * 8,
     "modal_aero_lw": lambda L: 26 * L * 8 + 16 * L * 8,
+    # history diagnostics of modal_aero_sw: the optics inputs once more + pmid, t, the UV / near-IR / all-band tauxar read
+    # back, 5 level fields and 35 column fields out
+    "modal_aero_sw_diag": lambda L: (26 + 2) * L * 8 + 14 * (L + 1) * 8 + 5 * L * 8 + 35 * 8,
 }
 
 
-def substep_bytes(L):
+def substep_bytes(L, sw_diag=True):
     return (BYTES["zm_convr"](L) + BYTES["zm_conv_evap"](L) + BYTES["momtran"](L) + 3 * BYTES["geopotential_t"](L)
-            + BYTES["modal_aero_sw"](L) + BYTES["modal_aero_lw"](L))
+            + BYTES["modal_aero_sw"](L) + BYTES["modal_aero_lw"](L) + (BYTES["modal_aero_sw_diag"](L) if sw_diag else 0))
 
 
 PMC_KERNEL = {"geopotential_t": "geopotential_kernel", "zm_trigger": "zm_trigger_kernel", "zm_plume1": "zm_plume1_kernel",
@@ -119,6 +122,9 @@ def main():
     ap.add_argument("--no-aero", action="store_true", help="configs[1]: ZM only (zm_convr + zm_conv_evap + momtran)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying a captured HIP graph")
+    ap.add_argument("--no-sw-diag", action="store_true",
+                    help="leave out modal_aero_sw's history diagnostics (modal_aer_opt.F90:896-993, 1046-1209), which the "
+                         "reference computes inside modal_aero_sw on every call: radiative outputs only")
     ap.add_argument("--lw-kernel", choices=["auto", "bands-outer", "grouped"], default="grouped",
                     help="kernel family of modal_aero_lw (colphys_aero_kernel_select); the substep is fastest with `grouped`")
     ap.add_argument("--serial", action="store_true", help="all kernels on one stream (no ZM || optics overlap)")
@@ -137,6 +143,7 @@ def main():
 
     pver = args.pver
     with_aero = not args.no_aero
+    sw_diag = with_aero and not args.no_sw_diag
     if args.strong:
         lo, hi = shard_range(args.ncol, world, rank)
         st_all = synth.make_state(args.ncol, pver, synth.DEFAULT_SEED)
@@ -194,6 +201,9 @@ def main():
         sw_out = {k: eng.empty(ncol, synth.NSWBANDS, pver + 1) for k in ("tauxar", "wa", "ga", "fa")}
         sw_out["status"] = eng.empty(ncol, dtype=torch.int32)
         lw_out = dict(tauxar=eng.empty(ncol, synth.NLWBANDS, pver), status=eng.empty(ncol, dtype=torch.int32))
+        if sw_diag:
+            A["troplevchem"] = d(aer["troplevchem"]).to(torch.int32)
+            swd_out = dict(lev=eng.empty(abi.SWD_NLEV, ncol, pver), col=eng.empty(abi.SWD_NCOL + abi.SWD_NMODEF * len(props["nspec"]), ncol))
 
     # The optics kernels share no data with the ZM chain, so they go on a second HIP stream and fill the SIMDs
     # the latency-bound ZM kernels leave idle (760 column groups, then ~80, on 1 024 SIMDs); --serial disables it.
@@ -206,6 +216,9 @@ def main():
 
     def aero():
         eng.modal_aero_sw(S["pdeldry"], A["specmmr"], A["dgnumwet"], A["qaerwat"], out=sw_out)
+        if sw_diag:                                 # what the reference's modal_aero_sw also computes, for outfld
+            eng.modal_aero_sw_diag(S["pdeldry"], S["pmid"], S["t"], A["specmmr"], A["dgnumwet"], A["qaerwat"], A["troplevchem"],
+                                   sw_out["tauxar"], out=swd_out)
         eng.modal_aero_lw(S["pdeldry"], A["specmmr"], A["dgnumwet"], A["qaerwat"], out=lw_out)
 
     step_start = torch.cuda.Event() if side is not None else None
@@ -273,6 +286,8 @@ def main():
             parts = [zm_out["ptend_s"].sum(), zm_out["prec"].sum(), zm_out["evapcdp"].sum(), zm_out["ptend_u"].sum(), zm_out["zm1"].sum()]
             if with_aero:
                 parts += [sw_out["tauxar"].sum(), lw_out["tauxar"].sum()]
+                if sw_diag:
+                    parts += [swd_out["col"].sum(), swd_out["lev"].sum()]
             return torch.stack(parts).cpu()
         fp_graph = fingerprint()
         substep()
@@ -317,8 +332,8 @@ def main():
                     "algorithmic_gb_per_launch": round(per_call[dom] * units / 1e9, 4),
                     "avg_launch_ms": round(kern_ms[dom], 4), "bytes_per_column": per_call[dom], "columns_per_launch": units,
                     "kernel_ms": {k: round(v, 4) for k, v in kern_ms.items()},
-                    "substep_bytes_per_column": substep_bytes(pver),
-                    "substep_hbm_frac": round(substep_bytes(pver) * value / world / 1e9 / HBM_PEAK_GBS, 6),
+                    "substep_bytes_per_column": substep_bytes(pver, with_aero and sw_diag),
+                    "substep_hbm_frac": round(substep_bytes(pver, with_aero and sw_diag) * value / world / 1e9 / HBM_PEAK_GBS, 6),
                     "note": "path is fp64-transcendental / latency bound, not HBM bound (SURVEY.md 0-4, 8d)",
                     "duration_source": "HIP events on the launch stream in a separate un-overlapped pass after the timed region; "
                                        "rocprofv3 of `bench.py --serial --no-graph` averages the same launches "
@@ -341,7 +356,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("ZM (zm_convr + zm_conv_evap + momtran) + 3x geopotential_t"
-                                    + (" + modal_aero_sw + modal_aero_lw" if with_aero else "")
+                                    + ((" + modal_aero_sw (with its history diagnostics)" if sw_diag else " + modal_aero_sw (radiative outputs only)")
+                                       + " + modal_aero_lw" if with_aero else "")
                                     + f", {args.ncol} columns x L{pver} per " + ("node" if args.strong else "GPU")),
                        "columns_per_rank": ncol, "pver": pver, "pcols": pcols, "deep_fraction": round(ndeep / ncol, 4),
                        "parallelism": f"static column split x{world}, no collectives on the data path",

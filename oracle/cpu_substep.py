@@ -44,7 +44,9 @@ def _substep(o, st, aer, lo, hi, c, dt, with_aero):
     chk = float(z["heat"].sum() + e["tend_q"].sum() + m["seten"].sum() + zm.sum())
     if with_aero:
         a = {k: (v[..., lo:hi, :] if k != "troplevchem" else v[lo:hi]) for k, v in aer.items()}
-        sw = o.modal_aero_sw(s, a)
+        sw = o.modal_aero_sw(s, a)                      # the reference's modal_aero_sw computes its history diagnostics inside
+        if not hasattr(o, "lib") or not hasattr(o.lib, "ref_dims"):      # the C restatement keeps them in a second function
+            chk += float(o.modal_aero_sw_diag(s, a)["col"].sum())
         lw = o.modal_aero_lw(s, a)
         chk += float(sw["tauxar"].sum() + lw["tauxar"].sum())
     return chk, int(z["lengath"].sum())
