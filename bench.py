@@ -203,6 +203,7 @@ def main():
         lw_out = dict(tauxar=eng.empty(ncol, synth.NLWBANDS, pver), status=eng.empty(ncol, dtype=torch.int32))
         if sw_diag:
             A["troplevchem"] = d(aer["troplevchem"]).to(torch.int32)
+            swd_vis = eng.empty(3, len(props["nspec"]), ncol, pver)     # visible-band optics per mode, SW kernel -> diagnostics
             swd_out = dict(lev=eng.empty(abi.SWD_NLEV, ncol, pver), col=eng.empty(abi.SWD_NCOL + abi.SWD_NMODEF * len(props["nspec"]), ncol))
 
     # The optics kernels share no data with the ZM chain, so they go on a second HIP stream and fill the SIMDs
@@ -215,10 +216,10 @@ def main():
         eng.aero_kernel_select("auto", args.lw_kernel)
 
     def aero():
-        eng.modal_aero_sw(S["pdeldry"], A["specmmr"], A["dgnumwet"], A["qaerwat"], out=sw_out)
+        eng.modal_aero_sw(S["pdeldry"], A["specmmr"], A["dgnumwet"], A["qaerwat"], out=sw_out, vis=swd_vis if sw_diag else None)
         if sw_diag:                                 # what the reference's modal_aero_sw also computes, for outfld
             eng.modal_aero_sw_diag(S["pdeldry"], S["pmid"], S["t"], A["specmmr"], A["dgnumwet"], A["qaerwat"], A["troplevchem"],
-                                   sw_out["tauxar"], out=swd_out)
+                                   sw_out["tauxar"], out=swd_out, vis=swd_vis)
         eng.modal_aero_lw(S["pdeldry"], A["specmmr"], A["dgnumwet"], A["qaerwat"], out=lw_out)
 
     step_start = torch.cuda.Event() if side is not None else None

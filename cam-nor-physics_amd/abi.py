@@ -173,7 +173,7 @@ class ModalAeroIO(C.Structure):
         [(n, PD) for n in ("pdeldry", "pmid", "t", "specmmr", "dgnumwet", "qaerwat")]
         + [("troplevchem", PI)]
         + [(n, PD) for n in ("tauxar", "wa", "ga", "fa")]
-        + [("status", PI)]
+        + [("status", PI), ("vis_optics", PD)]
     )
 
 

@@ -1226,7 +1226,7 @@ static int aero_chunks(bool sw, int nchunks, int pcols, int pver, const int32_t 
     if (diag && (!sw || !diag_lev || !diag_col || !io->pmid || !io->t || !io->troplevchem))
         return fail(COLPHYS_ERR_ARG, "SW diagnostics need lev, col, pmid, t and troplevchem");
     const int ncolf = COLPHYS_SWD_NCOL + COLPHYS_SWD_NMODEF * nm;
-    const size_t bytes = 8 * ncd * ((3 + (size_t)nm * (ns + 2)) * pver + 2 * nout + 8 + (diag ? 2 * ((size_t)COLPHYS_SWD_NLEV * pver + ncolf) : 0)) + 256 * 256;
+    const size_t bytes = 8 * ncd * ((3 + (size_t)nm * (ns + 2)) * pver + 2 * nout + 8 + (diag ? 2 * ((size_t)COLPHYS_SWD_NLEV * pver + ncolf) + 3 * (size_t)nm * pver : 0)) + 256 * 256;
     if ((rc = stage_reserve(bytes, bytes))) return rc;
     Stager s(nchunks, pcols, ncol, g_pin_arena.p, g_dev_arena.p);
     colphys_modal_aero_io d = *io;
@@ -1243,6 +1243,7 @@ static int aero_chunks(bool sw, int nchunks, int pcols, int pver, const int32_t 
     double *o[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int f = 0; f < (sw ? 4 : 1); ++f) o[f] = s.dc.take<double>(ncd * nb * nlevout);
     d.tauxar = o[0]; d.wa = o[1]; d.ga = o[2]; d.fa = o[3];
+    d.vis_optics = diag ? s.dc.take<double>(3 * (size_t)nm * ncd * pver) : nullptr;      // visible-band optics handed from SW to its diagnostics
     rc = sw ? colphys_modal_aero_sw_dev((int)ncd, pver, &d, nullptr) : colphys_modal_aero_lw_dev((int)ncd, pver, &d, nullptr);
     if (rc) return rc;
     double *dlev = nullptr, *dcol = nullptr;

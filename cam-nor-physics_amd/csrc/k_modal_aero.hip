@@ -233,7 +233,7 @@ __device__ __forceinline__ void slice_issue(const double *src, double *s_dst)
     }
 }
 
-template <bool SW, bool LUT>
+template <bool SW, bool LUT, bool VIS>
 __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev A, int ncol, int pver, int bands_per_group,
                                                        colphys_modal_aero_io io)
 {
@@ -337,6 +337,10 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
                 const double dopaer = pext * mass;
                 const double dw = (pext - pabs) * mass;                 // dopaer*palb without the quotient (see the bands-outer kernel)
                 if (dopaer <= -1.e-10 || dopaer >= 30.0) bad = 1;       // :997
+                if (VIS && ib == A.idx_sw_diag - 1 && live) {                     // hand-over to the diagnostics kernel
+                    double *vo = io.vis_optics + (size_t)m * F + cc;
+                    vo[0] = pext; vo[(size_t)A.nmodes * F] = pabs; vo[2 * (size_t)A.nmodes * F] = pasm;
+                }
                 double *acc = s_acc + (size_t)jb * 4 * NT + threadIdx.x;
                 acc[0] = acc[0] + dopaer;                               // :1032-1037
                 acc[NT] = acc[NT] + dw;
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
 // ------------------------------------------------------------------------------------------------------
 constexpr int NMMAX = 4;
 
-template <bool SW, bool LUT>
+template <bool SW, bool LUT, bool VIS>
 __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_aero_reg_kernel(AeroDev A, int ncol, int pver, colphys_modal_aero_io io)
 {
     constexpr int NTAB = SW ? 3 : 1;
@@ -491,10 +495,23 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
                 }
                 Wght wr, wi;
                 unit_weights<NTAB, LUT>(s_tbl, slices + gsl * SLICE, refr, refi, wr, wi);
+                double chm[NC];
+                if (VIS) {      // the hand-over stores need registers: keep only T1 of a mode and rebuild T2..T4 per unit (same
+                                // recurrence, same bits, six instructions) instead of spilling to scratch inside the band loop
+                                // (keeping T2 or T3 as well still spills)
+                    double x1 = cheb[m][1];
+                    asm volatile("" : "+v"(x1));    // opaque: or the rebuild is hoisted out of the band loop and T2..T4 are live again
+                    chm[0] = 1.0; chm[1] = x1;
+#pragma unroll
+                    for (int nc = 2; nc < NC; ++nc) chm[nc] = 2.0 * chm[1] * chm[nc - 1] - chm[nc - 2];
+                } else {
+#pragma unroll
+                    for (int nc = 0; nc < NC; ++nc) chm[nc] = cheb[m][nc];
+                }
                 if (SW) {
-                    double pext = interp_cheb(s_tbl, wr, wi, cheb[m]);
-                    double pabs = interp_cheb(s_tbl + TBLP, wr, wi, cheb[m]);
-                    const double pasm = interp_cheb(s_tbl + 2 * TBLP, wr, wi, cheb[m]);
+                    double pext = interp_cheb(s_tbl, wr, wi, chm);
+                    double pabs = interp_cheb(s_tbl + TBLP, wr, wi, chm);
+                    const double pasm = interp_cheb(s_tbl + 2 * TBLP, wr, wi, chm);
                     const double pe = cp_exp(pext);
                     pext = small[m] ? pe : 1.5 / (radsurf[m] * A.rhoh2o);
                     pext = pext * wetvol[m] * A.rhoh2o;
@@ -507,12 +524,19 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
                     const double dopaer = pext * mass;
                     const double dw = (pext - pabs) * mass;
                     if (dopaer <= -1.e-10 || dopaer >= 30.0) bad = 1;
+                    if (VIS && ib == A.idx_sw_diag - 1 && live) {                 // hand-over to the diagnostics kernel (uniform test)
+                        // uniform plane pointer + 32-bit byte offset of the cell (recomputed from col, k: nothing extra stays live)
+                        const unsigned boff = ((unsigned)col * (unsigned)pver + (unsigned)(k - 1)) * 8u;
+                        char *vo = (char *)(io.vis_optics + (size_t)m * F);
+                        const size_t VS = (size_t)A.nmodes * F * sizeof(double);
+                        *(double *)(vo + boff) = pext; *(double *)(vo + VS + boff) = pabs; *(double *)(vo + 2 * VS + boff) = pasm;
+                    }
                     a0 = a0 + dopaer;
                     a1 = a1 + dw;
                     a2 = a2 + dw * pasm;
                     a3 = a3 + dw * pasm * pasm;
                 } else {
-                    double pabs = interp_cheb(s_tbl, wr, wi, cheb[m]);  // :1386, 1390-1393
+                    double pabs = interp_cheb(s_tbl, wr, wi, chm);      // :1386, 1390-1393
                     pabs = pabs * wetvol[m] * A.rhoh2o;
                     pabs = fmax(0.0, pabs);
                     const double dopaer = pabs * mass;
@@ -788,6 +812,153 @@ __global__ __launch_bounds__(NT, DIAG_WAVES) void modal_aero_sw_diag_kernel(Aero
     }
 }
 
+// The same diagnostics from the visible-band optics the radiative kernel left in io.vis_optics (pext, pabs, pasm per mode):
+// no tables, no slices, no size parameters -- what remains per mode is the species bookkeeping, the partition and the
+// column sums, at a third of the registers (five waves per SIMD instead of two).
+__global__ __launch_bounds__(NT, 4) void modal_aero_sw_diag_vis_kernel(AeroDev A, int ncol, int pver, int cpb, colphys_modal_aero_io io,
+                                                                        double *__restrict__ lev, double *__restrict__ colf)
+{
+    extern __shared__ double smem[];
+    double *s_red = smem;                              // [DIAG_ROUND][DIAG_STRIDE]: 17 KB, occupancy is then the registers'
+    const int nb = A.nswbands, ivis = A.idx_sw_diag - 1;
+    const size_t L = (size_t)pver, F = (size_t)ncol * L;
+    const int tid = threadIdx.x;
+    const int cl = tid / pver, k = tid - cl * pver + 1;
+    const int col = blockIdx.x * cpb + cl;
+    const bool live = cl < cpb && col < ncol;
+    const size_t cc = live ? (size_t)col * L + (k - 1) : F - 1;
+    const bool active = live && k >= A.top_lev;
+    const double rh2odens = 1.0 / A.rhoh2o;
+    const int sq = tid & (DIAG_PARTS - 1), sj = (tid >> 2) & (DIAG_ROUND - 1), src = tid >> 5;
+    const int nred = min(cpb, ncol - (int)blockIdx.x * cpb);
+    const bool writer = sq == 0 && src < nred;
+    const size_t wcol = (size_t)blockIdx.x * cpb + src;
+
+    const double mass = io.pdeldry[cc] * A.rga;                         // :644
+    const double air_density = io.pmid[cc] / (A.rair * io.t[cc]);       // :645
+    const double ad_mass = air_density / mass;
+    const bool strat = live && k <= io.troplevchem[live ? col : 0];
+    double extinct = 0.0, absorb = 0.0, asymext = 0.0;
+    double acc0 = 0.0;
+    // burdens and optical depths by species type: the cell's sums over the modes stay in registers and the column sums
+    // are taken once after the mode loop (levels outer, modes inner: a reassociation of the reference's mode-outer sums
+    // of non-negative terms); the plain visible-band sums and the per-mode fields are summed mode by mode
+    double c_bur[NTYPE], c_aod[NTYPE];
+#pragma unroll
+    for (int ty = 0; ty < NTYPE; ++ty) { c_bur[ty] = 0.0; c_aod[ty] = 0.0; }
+    const size_t VS = (size_t)A.nmodes * F;
+
+    for (int m = 0; m < A.nmodes; ++m) {                                // :706
+        const int nspec = as_const(A.nspec)[m];
+        const double qw = io.qaerwat[m * F + cc];
+        const double pext = io.vis_optics[m * F + cc], pabs = io.vis_optics[VS + m * F + cc], pasm = io.vis_optics[2 * VS + m * F + cc];
+        double v[NSMAX];
+#pragma unroll
+        for (int l = 0; l < NSMAX; ++l) {
+            v[l] = 0.0;
+            if (l < nspec) v[l] = io.specmmr[((size_t)m * A.nspec_max + l) * F + cc];
+        }
+        cptr_t ri = as_const(A.specrefindex_sw + ((size_t)m * A.nspec_max * nb + ivis) * 2);
+        double dryvol = 0.0, burden = 0.0;
+#pragma unroll
+        for (int l = 0; l < NSMAX; ++l) {
+            if (l < nspec) {
+                const double bm = active ? v[l] * mass : 0.0;           // :777
+                burden = burden + bm;
+                const int sty = as_const(A.spectype)[m * A.nspec_max + l];
+#pragma unroll
+                for (int ty = 0; ty < NTYPE; ++ty) c_bur[ty] = c_bur[ty] + ((sty == ty) ? 1.0 : 0.0) * bm;
+                v[l] = v[l] * as_const(A.rspecdens)[m * A.nspec_max + l];
+                dryvol = dryvol + v[l];
+            }
+        }
+        double watervol = qw * rh2odens;                                // :835-844
+        double wetvol = watervol + dryvol;
+        if (watervol < 0.0) { watervol = 0.0; wetvol = dryvol; }
+        const double wetinv = 1.0 / fmax(wetvol, 1.e-60);
+        cptr_t crefw = as_const(A.crefwsw + ivis * 2);
+        const double cwr = crefw[0], cwi = crefw[1];
+        const double palb = 1.0 - pabs / fmax(pext, 1.e-40);
+        const double dopaer = active ? pext * mass : 0.0;
+
+        extinct = extinct + dopaer * ad_mass;                           // :921-934
+        absorb = absorb + pabs * air_density;
+        asymext = asymext + dopaer * pasm * ad_mass;
+        if (m > 0) __syncthreads();                                     // the previous mode's sums have been taken
+        s_red[0 * DIAG_STRIDE + tid] = dopaer;
+        s_red[1 * DIAG_STRIDE + tid] = active ? pabs * mass : 0.0;
+        s_red[2 * DIAG_STRIDE + tid] = dopaer * palb;
+        s_red[3 * DIAG_STRIDE + tid] = dopaer * pasm;
+        s_red[5 * DIAG_STRIDE + tid] = strat ? dopaer : 0.0;
+        s_red[6 * DIAG_STRIDE + tid] = burden;
+        double absbc = 0.0, dustaod_m = 0.0;
+        if (wetvol > 1.e-40) {                                          // :936-990, as in the kernel above
+            const int lastmask = as_const(A.lastmask)[m];
+            const double scath2o = watervol * cwr, absh2o = -(watervol * cwi);
+            double sumscat = 0.0, sumabs = 0.0, sumhygro = 0.0;
+#pragma unroll
+            for (int l = 0; l < NSMAX; ++l) {
+                if (l < nspec && ((lastmask >> l) & 1)) {
+                    sumscat = sumscat + v[l] * ri[(size_t)l * nb * 2];
+                    sumabs = sumabs - v[l] * ri[(size_t)l * nb * 2 + 1];
+                    sumhygro = sumhygro + v[l] * as_const(A.hygro)[m * A.nspec_max + l];
+                }
+            }
+            sumscat = sumscat + scath2o;
+            sumabs = sumabs + absh2o;
+            const double rscat = 1.0 / sumscat, rabs = 1.0 / sumabs, rhyg = 1.0 / sumhygro;
+            const double wsc = scath2o * rhyg, wab = absh2o * rhyg;
+            const double ssa_d = palb * dopaer * rscat, abs_d = (1.0 - palb) * dopaer * rabs;
+#pragma unroll
+            for (int l = 0; l < NSMAX; ++l) {
+                if (l < nspec && ((lastmask >> l) & 1)) {
+                    const int sty = as_const(A.spectype)[m * A.nspec_max + l];
+                    const double hy = as_const(A.hygro)[m * A.nspec_max + l];
+                    const double ab = (wab * hy - ri[(size_t)l * nb * 2 + 1]) * v[l] * abs_d;
+                    const double sc = (wsc * hy + ri[(size_t)l * nb * 2]) * v[l] * ssa_d;
+#pragma unroll
+                    for (int ty = 0; ty < NTYPE; ++ty) c_aod[ty] = c_aod[ty] + ((sty == ty) ? 1.0 : 0.0) * (ab + sc);
+                    absbc = absbc + ((sty == 3) ? 1.0 : 0.0) * ab;
+                    dustaod_m = dustaod_m + ((sty == 4) ? 1.0 : 0.0) * (dopaer * v[l] * wetinv);
+                }
+            }
+        }
+        s_red[4 * DIAG_STRIDE + tid] = absbc;
+        s_red[7 * DIAG_STRIDE + tid] = dustaod_m;
+        __syncthreads();
+        {
+            const double a = level_sums(s_red, nred, pver);
+            if (sj < 6) acc0 = acc0 + a;
+            if (writer && sj == 0) colf[(size_t)(COLPHYS_SWD_NCOL + COLPHYS_SWD_NMODEF * m + 1) * ncol + wcol] = a;
+            if (writer && sj == 6) colf[(size_t)(COLPHYS_SWD_NCOL + COLPHYS_SWD_NMODEF * m + 0) * ncol + wcol] = a;
+            if (writer && sj == 7) colf[(size_t)(COLPHYS_SWD_NCOL + COLPHYS_SWD_NMODEF * m + 2) * ncol + wcol] = a;
+        }
+    }
+    double acc1, acc2;
+    __syncthreads();
+#pragma unroll
+    for (int ty = 0; ty < NTYPE; ++ty) s_red[ty * DIAG_STRIDE + tid] = c_bur[ty];
+    __syncthreads();
+    acc1 = (sj < NTYPE) ? level_sums(s_red, nred, pver) : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int ty = 0; ty < NTYPE; ++ty) s_red[ty * DIAG_STRIDE + tid] = c_aod[ty];
+    __syncthreads();
+    acc2 = (sj < NTYPE) ? level_sums(s_red, nred, pver) : 0.0;
+    if (live) {
+        const size_t o = (size_t)col * L + (k - 1);
+        lev[(size_t)COLPHYS_SWD_LEV_EXTINCT * F + o] = active ? extinct : 0.0;
+        lev[(size_t)COLPHYS_SWD_LEV_ABSORB * F + o] = active ? absorb : 0.0;
+        lev[(size_t)COLPHYS_SWD_LEV_ASYMEXT * F + o] = active ? asymext : 0.0;
+    }
+    if (writer) {
+        const int f0 = diag_slot_field[sj], f1 = diag_slot_field[DIAG_ROUND + sj], f2 = diag_slot_field[2 * DIAG_ROUND + sj];
+        if (f0 >= 0) colf[(size_t)f0 * ncol + wcol] = acc0;
+        if (f1 >= 0) colf[(size_t)f1 * ncol + wcol] = acc1;
+        if (f2 >= 0) colf[(size_t)f2 * ncol + wcol] = acc2;
+    }
+}
+
 // AODTOT and the UV / near-IR fields (:896-917): sums over the modes of dopaer, i.e. the radiative kernel's tauxar.  A
 // streaming kernel of its own (same block shape and column sums as above) so that its fourteen loads per cell do not
 // sit behind the table work in the two-waves-per-SIMD kernel above.
@@ -895,15 +1066,19 @@ static int launch_aero(bool sw, const AeroDev &A, int ncol, int pver, const colp
         // LDS: the slice double buffer + the species volumes of all modes, [sum of nspec][NT] (nspec lives on the device:
         // size for the largest table the engine accepts would waste LDS, so the host mirror of nspec is used)
         const size_t lds_reg = (2 * slice + (size_t)A.nspec_total * NT) * sizeof(double);
-        auto kern = sw ? (A.lut_ok_sw ? modal_aero_reg_kernel<true, true> : modal_aero_reg_kernel<true, false>)
-                       : (A.lut_ok_lw ? modal_aero_reg_kernel<false, true> : modal_aero_reg_kernel<false, false>);
+        const bool vis = sw && io.vis_optics != nullptr;     // template parameter: the hand-over stores cost the plain kernel registers
+        auto kern = sw ? (A.lut_ok_sw ? (vis ? modal_aero_reg_kernel<true, true, true> : modal_aero_reg_kernel<true, true, false>)
+                                      : (vis ? modal_aero_reg_kernel<true, false, true> : modal_aero_reg_kernel<true, false, false>))
+                       : (A.lut_ok_lw ? modal_aero_reg_kernel<false, true, false> : modal_aero_reg_kernel<false, false, false>);
         if (lds_reg > 64 * 1024)
             hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
         hipLaunchKernelGGL(kern, g1, dim3(NT), lds_reg, st, A, ncol, pver, io);
         return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
     }
-    auto kern = sw ? (A.lut_ok_sw ? modal_aero_kernel<true, true> : modal_aero_kernel<true, false>)
-                   : (A.lut_ok_lw ? modal_aero_kernel<false, true> : modal_aero_kernel<false, false>);
+    const bool vis = sw && io.vis_optics != nullptr;
+    auto kern = sw ? (A.lut_ok_sw ? (vis ? modal_aero_kernel<true, true, true> : modal_aero_kernel<true, true, false>)
+                                  : (vis ? modal_aero_kernel<true, false, true> : modal_aero_kernel<true, false, false>))
+                   : (A.lut_ok_lw ? modal_aero_kernel<false, true, false> : modal_aero_kernel<false, false, false>);
     if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, A, ncol, pver, bpg, io);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
@@ -925,10 +1100,15 @@ int launch_modal_aero_sw_diag(const AeroDev &A, int ncol, int pver, const colphy
     const int cpb = std::min(NT / pver, DIAG_CPB);
     const size_t lds = (2 * (size_t)aero_slice_doubles(3) + (size_t)DIAG_NSLOT * DIAG_STRIDE) * sizeof(double);
     if (lds > 160 * 1024) return COLPHYS_ERR_UNSUPPORTED;
-    auto kern = A.lut_ok_sw ? modal_aero_sw_diag_kernel<true> : modal_aero_sw_diag_kernel<false>;
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const dim3 grid((unsigned)((ncol + cpb - 1) / cpb));
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, A, ncol, pver, cpb, io, lev, col);
+    if (io.vis_optics) {                    // the radiative kernel left the visible-band optics: no second table evaluation
+        const size_t lds_v = (size_t)DIAG_ROUND * DIAG_STRIDE * sizeof(double);
+        hipLaunchKernelGGL(modal_aero_sw_diag_vis_kernel, grid, dim3(NT), lds_v, st, A, ncol, pver, cpb, io, lev, col);
+    } else {
+        auto kern = A.lut_ok_sw ? modal_aero_sw_diag_kernel<true> : modal_aero_sw_diag_kernel<false>;
+        if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, A, ncol, pver, cpb, io, lev, col);
+    }
     hipLaunchKernelGGL(modal_aero_sw_diag_tau_kernel, grid, dim3(NT), 0, st, A, ncol, pver, cpb, io, lev, col);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }

@@ -337,20 +337,23 @@ class ColumnPhysics:
         io.t = _p(t) if t is not None else None
         return io
 
-    def modal_aero_sw(self, pdeldry, specmmr, dgnumwet, qaerwat, out=None):
+    def modal_aero_sw(self, pdeldry, specmmr, dgnumwet, qaerwat, out=None, vis=None):
+        """vis: optional [3][nmodes][n][pver] buffer for the visible-band optics per mode, which modal_aero_sw_diag then reads
+        instead of evaluating the tables again (colphys_modal_aero_io.vis_optics)"""
         n, pver = pdeldry.shape
         nsw = self.tables.nswbands
         if out is None:
             out = {k: self.empty(n, nsw, pver + 1) for k in ("tauxar", "wa", "ga", "fa")}
             out["status"] = self.empty(n, dtype=self.torch.int32)
         io = self._aero_io(pdeldry, specmmr, dgnumwet, qaerwat)
+        io.vis_optics = _p(self._f64(vis)) if vis is not None else None
         for k in ("tauxar", "wa", "ga", "fa"):
             setattr(io, k, _p(out[k]))
         io.status = _p(out["status"], abi.PI)
         self._check(self.lib.colphys_modal_aero_sw_dev(C.c_int(n), C.c_int(pver), C.byref(io), self._stream()))
         return out
 
-    def modal_aero_sw_diag(self, pdeldry, pmid, t, specmmr, dgnumwet, qaerwat, troplevchem, tauxar, out=None):
+    def modal_aero_sw_diag(self, pdeldry, pmid, t, specmmr, dgnumwet, qaerwat, troplevchem, tauxar, out=None, vis=None):
         """modal_aero_sw's history diagnostics (modal_aer_opt.F90:896-993, 1046-1154), after modal_aero_sw has filled
         `tauxar`.  Returns lev [SWD_NLEV][n][pver] and col [SWD_NCOL + 3*nmodes][n] in the field order of
         abi.SWD_LEV_FIELDS / abi.SWD_COL_FIELDS (+ burden, aodmode, dustaodmode per mode)."""
@@ -360,6 +363,7 @@ class ColumnPhysics:
         io = self._aero_io(pdeldry, specmmr, dgnumwet, qaerwat, self._f64(pmid), self._f64(t))
         io.troplevchem = _p(troplevchem, abi.PI)
         io.tauxar = _p(self._f64(tauxar))
+        io.vis_optics = _p(self._f64(vis)) if vis is not None else None
         self._check(self.lib.colphys_modal_aero_sw_diag_dev(C.c_int(n), C.c_int(pver), C.byref(io), _p(out["lev"]), _p(out["col"]),
                                                             self._stream()))
         return out

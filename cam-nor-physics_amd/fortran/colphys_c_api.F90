@@ -62,6 +62,7 @@ module colphys_c_api
     type(c_ptr) :: troplevchem
     type(c_ptr) :: tauxar, wa, ga, fa
     type(c_ptr) :: status
+    type(c_ptr) :: vis_optics = c_null_ptr
   end type colphys_modal_aero_io
 
   interface

@@ -63,7 +63,7 @@
 extern "C" {
 #endif
 
-#define COLPHYS_ABI_VERSION 2
+#define COLPHYS_ABI_VERSION 3
 
 #define COLPHYS_OK             0
 #define COLPHYS_ERR_ARG      (-1)
@@ -365,6 +365,11 @@ typedef struct colphys_modal_aero_io {
     double *tauxar, *wa, *ga, *fa;
     /* LW out: [ncol][nlwbands][pver]; pass through tauxar (wa/ga/fa NULL) */
     int32_t *status;                      /* [ncol] */
+    /* optional (NULL: not used): [3][nmodes][ncol][pver] -- per mode, at the visible band idx_sw_diag, the specific
+     * extinction and absorption as they enter dopaer (modal_aer_opt.F90:881, 888-890: scaled by wetvol*rhoh2o, absorption
+     * clamped to [0, extinction]) and the asymmetry factor (:883-887).  Written by colphys_modal_aero_sw_dev, read by
+     * colphys_modal_aero_sw_diag_dev, which then does not evaluate the tables a second time. */
+    double *vis_optics;
 } colphys_modal_aero_io;
 
 /* Which of the two kernel families serves modal_aero_sw / modal_aero_lw (same results to rounding; both are tested against

@@ -24,11 +24,14 @@ eng.aero_tables_set(props, synth.PHYSCONST)
 d = eng.dev
 a = (d(st["pdeldry"]), d(aer["specmmr"]), d(aer["dgnumwet"]), d(aer["qaerwat"]))
 pm, t, tl = d(st["pmid"]), d(st["t"]), d(aer["troplevchem"].astype(np.int32))
-sw = eng.modal_aero_sw(*a)
-out = eng.modal_aero_sw_diag(a[0], pm, t, a[1], a[2], a[3], tl, sw["tauxar"])
+vis = eng.empty(3, eng.tables.nmodes, ncol, pver)
+sw = eng.modal_aero_sw(*a, vis=vis)
+out = eng.modal_aero_sw_diag(a[0], pm, t, a[1], a[2], a[3], tl, sw["tauxar"], vis=vis)
 torch.cuda.synchronize()
 for name, fn in (("modal_aero_sw", lambda: eng.modal_aero_sw(*a, out=sw)),
-                 ("modal_aero_sw_diag", lambda: eng.modal_aero_sw_diag(a[0], pm, t, a[1], a[2], a[3], tl, sw["tauxar"], out=out))):
+                 ("modal_aero_sw + hand-over", lambda: eng.modal_aero_sw(*a, out=sw, vis=vis)),
+                 ("modal_aero_sw_diag (tables)", lambda: eng.modal_aero_sw_diag(a[0], pm, t, a[1], a[2], a[3], tl, sw["tauxar"], out=out)),
+                 ("modal_aero_sw_diag (hand-over)", lambda: eng.modal_aero_sw_diag(a[0], pm, t, a[1], a[2], a[3], tl, sw["tauxar"], out=out, vis=vis))):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(3):
         fn()
@@ -37,4 +40,4 @@ for name, fn in (("modal_aero_sw", lambda: eng.modal_aero_sw(*a, out=sw)),
         fn()
     e1.record()
     torch.cuda.synchronize()
-    print(f"{name:22s} L{pver}: {e0.elapsed_time(e1) / 20:.4f} ms")
+    print(f"{name:32s} L{pver}: {e0.elapsed_time(e1) / 20:.4f} ms")

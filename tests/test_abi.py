@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/colphys.h but not exported by {LIB}"
     assert set(EXPORTED_SYMBOLS) == set(syms)
-    assert lib.colphys_abi_version() == 2
+    assert lib.colphys_abi_version() == 3
 
 
 def test_gfx950_code_object_is_embedded():

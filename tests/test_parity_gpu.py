@@ -262,12 +262,16 @@ def test_modal_aero_vs_reference_golden(name, family):
     assert (sw["tauxar"] >= 0).all() and (lw["tauxar"] >= 0).all()
 
 
-def _swd_engine(eng, st, aer):
-    """modal_aero_sw followed by its history diagnostics on the engine; numpy lev / col"""
+def _swd_engine(eng, st, aer, hand_over=True):
+    """modal_aero_sw followed by its history diagnostics on the engine; numpy lev / col.  hand_over: modal_aero_sw leaves the
+    visible-band optics per mode for the diagnostics (colphys_modal_aero_io.vis_optics); else they evaluate the tables again"""
     d = eng.dev
     a = (d(st["pdeldry"]), d(aer["specmmr"]), d(aer["dgnumwet"]), d(aer["qaerwat"]))
-    sw = eng.modal_aero_sw(*a)
-    dg = eng.modal_aero_sw_diag(a[0], d(st["pmid"]), d(st["t"]), a[1], a[2], a[3], d(aer["troplevchem"].astype(np.int32)), sw["tauxar"])
+    n, pver = st["pdeldry"].shape
+    vis = eng.empty(3, eng.tables.nmodes, n, pver) if hand_over else None
+    sw = eng.modal_aero_sw(*a, vis=vis)
+    dg = eng.modal_aero_sw_diag(a[0], d(st["pmid"]), d(st["t"]), a[1], a[2], a[3], d(aer["troplevchem"].astype(np.int32)), sw["tauxar"],
+                                vis=vis)
     return to_np(dg)
 
 
@@ -279,8 +283,9 @@ def _assert_swd(got, want_lev, want_col, nmodes):
         assert_close(nm, got["col"][f], want_col[f])
 
 
+@pytest.mark.parametrize("hand_over", [True, False])
 @pytest.mark.parametrize("name", cases.AERO_GOLDEN)
-def test_modal_aero_sw_diagnostics_vs_reference_golden(name):
+def test_modal_aero_sw_diagnostics_vs_reference_golden(name, hand_over):
     """modal_aero_sw's history diagnostics (modal_aer_opt.F90:896-993, 1046-1154) against what the reference build handed to
     outfld ("dn" fields; SSAVISdn finished the reference's way on the caller side, cases.swd_reference_ssavis).
     Tolerance 1e-10 relative (tests/util.py); AODTOT / UV / near-IR come from tauxar, i.e. summed over modes first."""
@@ -290,7 +295,7 @@ def test_modal_aero_sw_diagnostics_vs_reference_golden(name):
     eng.aero_tables_set(synth.make_aero_props(int(g["seed"])), synth.PHYSCONST)
     st = dict(pdeldry=g["in_pdeldry"], pmid=g["in_pmid"], t=g["in_t"])
     aer = {k: g["in_" + k] for k in ("specmmr", "dgnumwet", "qaerwat", "troplevchem")}
-    dg = _swd_engine(eng, st, aer)
+    dg = _swd_engine(eng, st, aer, hand_over)
     dg["col"] = cases.swd_reference_ssavis(dg["col"], g["in_nite"])
     _assert_swd(dg, g["swd_lev"], g["swd_col"], eng.tables.nmodes)
 
@@ -385,8 +390,9 @@ def test_modal_aero_vs_c_oracle(top_lev):
         assert sw["tauxar"][:, :, top_lev:].all()
 
 
+@pytest.mark.parametrize("hand_over", [True, False])
 @pytest.mark.parametrize("pver,ncol,top_lev", [(32, 701, 1), (32, 203, 4), (70, 100, 1), (26, 37, 2)])
-def test_modal_aero_sw_diagnostics_vs_c_oracle(pver, ncol, top_lev):
+def test_modal_aero_sw_diagnostics_vs_c_oracle(pver, ncol, top_lev, hand_over):
     """ragged column counts (blocks own NT/pver columns: 8, 3, 9 per block here), top_lev > 1, tropopause anywhere
     including above the top level and below the surface"""
     from c_oracle import COracle
@@ -403,7 +409,7 @@ def test_modal_aero_sw_diagnostics_vs_c_oracle(pver, ncol, top_lev):
     aer["qaerwat"][:, ::9, :] *= -1.0                             # negative water: watervol reset before the partition
     eng.aero_tables_set(props, synth.PHYSCONST)
     co.aero_tables_set(props, synth.PHYSCONST)
-    got, want = _swd_engine(eng, st, aer), co.modal_aero_sw_diag(st, aer)
+    got, want = _swd_engine(eng, st, aer, hand_over), co.modal_aero_sw_diag(st, aer)
     _assert_swd(got, want["lev"], want["col"], eng.tables.nmodes)
     if top_lev > 1:
         assert not got["lev"][:, :, :top_lev - 1].any()
