@@ -838,6 +838,14 @@ __global__ __launch_bounds__(NT, 4) void modal_aero_sw_diag_vis_kernel(AeroDev A
     const double air_density = io.pmid[cc] / (A.rair * io.t[cc]);       // :645
     const double ad_mass = air_density / mass;
     const bool strat = live && k <= io.troplevchem[live ? col : 0];
+    // AODTOT and the UV / near-IR fields (:896-917) are sums over the modes of dopaer, i.e. the radiative kernel's tauxar
+    double t_tot = 0.0, t_uv = 0.0, t_nir = 0.0;
+    if (active) {
+        const double *tau = io.tauxar + (size_t)col * nb * (L + 1) + k;
+        for (int ib = 0; ib < nb; ++ib) t_tot = t_tot + tau[(size_t)ib * (L + 1)];
+        t_uv = tau[(size_t)(A.idx_uv_diag - 1) * (L + 1)];
+        t_nir = tau[(size_t)(A.idx_nir_diag - 1) * (L + 1)];
+    }
     double extinct = 0.0, absorb = 0.0, asymext = 0.0;
     double acc0 = 0.0;
     // burdens and optical depths by species type: the cell's sums over the modes stay in registers and the column sums
@@ -945,11 +953,26 @@ __global__ __launch_bounds__(NT, 4) void modal_aero_sw_diag_vis_kernel(AeroDev A
     for (int ty = 0; ty < NTYPE; ++ty) s_red[ty * DIAG_STRIDE + tid] = c_aod[ty];
     __syncthreads();
     acc2 = (sj < NTYPE) ? level_sums(s_red, nred, pver) : 0.0;
+    __syncthreads();
+    s_red[0 * DIAG_STRIDE + tid] = t_tot;
+    s_red[1 * DIAG_STRIDE + tid] = t_uv;
+    s_red[2 * DIAG_STRIDE + tid] = t_nir;
+    s_red[3 * DIAG_STRIDE + tid] = strat ? t_uv : 0.0;
+    s_red[4 * DIAG_STRIDE + tid] = strat ? t_nir : 0.0;
+    __syncthreads();
+    const double acc3 = (sj < 5) ? level_sums(s_red, nred, pver) : 0.0;
     if (live) {
         const size_t o = (size_t)col * L + (k - 1);
         lev[(size_t)COLPHYS_SWD_LEV_EXTINCT * F + o] = active ? extinct : 0.0;
         lev[(size_t)COLPHYS_SWD_LEV_ABSORB * F + o] = active ? absorb : 0.0;
         lev[(size_t)COLPHYS_SWD_LEV_ASYMEXT * F + o] = active ? asymext : 0.0;
+        lev[(size_t)COLPHYS_SWD_LEV_EXTINCTUV * F + o] = active ? t_uv * ad_mass : 0.0;
+        lev[(size_t)COLPHYS_SWD_LEV_EXTINCTNIR * F + o] = active ? t_nir * ad_mass : 0.0;
+    }
+    if (writer && sj < 5) {
+        const int f3 = sj == 0 ? COLPHYS_SWD_COL_AODTOT : sj == 1 ? COLPHYS_SWD_COL_AODUV : sj == 2 ? COLPHYS_SWD_COL_AODNIR
+                     : sj == 3 ? COLPHYS_SWD_COL_AODUVST : COLPHYS_SWD_COL_AODNIRST;
+        colf[(size_t)f3 * ncol + wcol] = acc3;
     }
     if (writer) {
         const int f0 = diag_slot_field[sj], f1 = diag_slot_field[DIAG_ROUND + sj], f2 = diag_slot_field[2 * DIAG_ROUND + sj];
@@ -1108,7 +1131,7 @@ int launch_modal_aero_sw_diag(const AeroDev &A, int ncol, int pver, const colphy
         auto kern = A.lut_ok_sw ? modal_aero_sw_diag_kernel<true> : modal_aero_sw_diag_kernel<false>;
         if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, A, ncol, pver, cpb, io, lev, col);
+        hipLaunchKernelGGL(modal_aero_sw_diag_tau_kernel, grid, dim3(NT), 0, st, A, ncol, pver, cpb, io, lev, col);
     }
-    hipLaunchKernelGGL(modal_aero_sw_diag_tau_kernel, grid, dim3(NT), 0, st, A, ncol, pver, cpb, io, lev, col);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
