@@ -125,8 +125,10 @@ def main():
     ap.add_argument("--no-sw-diag", action="store_true",
                     help="leave out modal_aero_sw's history diagnostics (modal_aer_opt.F90:896-993, 1046-1209), which the "
                          "reference computes inside modal_aero_sw on every call: radiative outputs only")
-    ap.add_argument("--lw-kernel", choices=["auto", "bands-outer", "grouped"], default="grouped",
-                    help="kernel family of modal_aero_lw (colphys_aero_kernel_select); the substep is fastest with `grouped`")
+    ap.add_argument("--lw-kernel", choices=["auto", "bands-outer", "grouped"], default="auto",
+                    help="kernel family of modal_aero_lw (colphys_aero_kernel_select).  auto = bands-outer: with the SW diagnostics "
+                         "in the substep the optics stream ends last and the kernel that is faster alone wins (2.425 against 2.453 ms); "
+                         "with --no-sw-diag `grouped` measures 0.6 %% faster")
     ap.add_argument("--serial", action="store_true", help="all kernels on one stream (no ZM || optics overlap)")
     args = ap.parse_args()
 
@@ -210,9 +212,8 @@ def main():
     # the latency-bound ZM kernels leave idle (760 column groups, then ~80, on 1 024 SIMDs); --serial disables it.
     side = torch.cuda.Stream(priority=0) if (with_aero and not args.serial) else None
     if with_aero:
-        # beside the ZM chain the grouped LW kernel measures 0.6 % faster per substep than the bands-outer one, which is 15 %
-        # faster alone (include/colphys.h colphys_aero_kernel_select; A/B in DESIGN.md section 4).  The same kernels run in
-        # the --serial passes the profiles are taken from.
+        # kernel family of the LW optics (include/colphys.h colphys_aero_kernel_select; A/Bs in DESIGN.md section 4).  The same
+        # kernels run in the --serial passes the profiles are taken from.
         eng.aero_kernel_select("auto", args.lw_kernel)
 
     def aero():

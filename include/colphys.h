@@ -376,8 +376,9 @@ typedef struct colphys_modal_aero_io {
  * the same goldens).  AUTO = BANDS_OUTER when the tables have at most four modes, else GROUPED.  BANDS_OUTER keeps every
  * mode's size / volume state of a cell and walks the bands once: fastest alone (the call pattern of the radiation driver).
  * GROUPED walks modes outer / a band group inner with LDS accumulators: for LW it is 15 % slower alone but leaves the CUs'
- * LDS and wave slots freer, which measures 0.6 % faster when the optics run BESIDE the ZM chain on a second stream
- * (bench.py's substep). */
+ * LDS and wave slots freer, which can pay when the optics run BESIDE the ZM chain on a second stream and the chain is the
+ * longer of the two (bench.py --no-sw-diag: 0.6 % per substep; with the SW diagnostics the optics stream is the longer one
+ * and BANDS_OUTER wins by 1.1 %). */
 #define COLPHYS_AERO_KERNEL_AUTO        0
 #define COLPHYS_AERO_KERNEL_BANDS_OUTER 1
 #define COLPHYS_AERO_KERNEL_GROUPED     2

@@ -28,16 +28,19 @@ vis = eng.empty(3, eng.tables.nmodes, ncol, pver)
 sw = eng.modal_aero_sw(*a, vis=vis)
 out = eng.modal_aero_sw_diag(a[0], pm, t, a[1], a[2], a[3], tl, sw["tauxar"], vis=vis)
 torch.cuda.synchronize()
-for name, fn in (("modal_aero_sw", lambda: eng.modal_aero_sw(*a, out=sw)),
-                 ("modal_aero_sw + hand-over", lambda: eng.modal_aero_sw(*a, out=sw, vis=vis)),
-                 ("modal_aero_sw_diag (tables)", lambda: eng.modal_aero_sw_diag(a[0], pm, t, a[1], a[2], a[3], tl, sw["tauxar"], out=out)),
-                 ("modal_aero_sw_diag (hand-over)", lambda: eng.modal_aero_sw_diag(a[0], pm, t, a[1], a[2], a[3], tl, sw["tauxar"], out=out, vis=vis))):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+# durations from the library's own HIP events around each launch (colphys_profile_*), 20 launches each
+eng.profile_enable(True)
+for name, key, fn in (("modal_aero_sw", "modal_aero_sw", lambda: eng.modal_aero_sw(*a, out=sw)),
+                      ("modal_aero_sw + hand-over", "modal_aero_sw", lambda: eng.modal_aero_sw(*a, out=sw, vis=vis)),
+                      ("modal_aero_sw_diag (tables)", "modal_aero_sw_diag",
+                       lambda: eng.modal_aero_sw_diag(a[0], pm, t, a[1], a[2], a[3], tl, sw["tauxar"], out=out)),
+                      ("modal_aero_sw_diag (hand-over)", "modal_aero_sw_diag",
+                       lambda: eng.modal_aero_sw_diag(a[0], pm, t, a[1], a[2], a[3], tl, sw["tauxar"], out=out, vis=vis))):
     for _ in range(3):
         fn()
-    e0.record()
+    torch.cuda.synchronize()
+    eng.profile_reset()
     for _ in range(20):
         fn()
-    e1.record()
     torch.cuda.synchronize()
-    print(f"{name:32s} L{pver}: {e0.elapsed_time(e1) / 20:.4f} ms")
+    print(f"{name:32s} L{pver}: {eng.profile()[key][0]:.4f} ms")
