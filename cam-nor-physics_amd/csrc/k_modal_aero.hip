@@ -465,6 +465,22 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
         }
     }
     __syncthreads();
+    // Hand-over of the visible-band optics (VIS): the three values of a unit are stored at the START of the next unit, i.e.
+    // right behind the barrier, not in front of it (stores count in vmcnt like the slice DMA, and a barrier waits for
+    // vmcnt(0)).  The variant measures 3-5 % slower than the plain kernel alone, whatever the placement of the stores.
+    double hv0 = 0.0, hv1 = 0.0, hv2 = 0.0;
+    int hm = -1;                                        // mode whose values are pending (wave-uniform)
+    auto hand_over_store = [&]() {
+        if (live) {
+            // uniform plane pointer + 32-bit byte offset of the cell (recomputed from col, k: nothing extra stays live)
+            unsigned boff = ((unsigned)col * (unsigned)pver + (unsigned)(k - 1)) * 8u;
+            asm volatile("" : "+v"(boff));              // opaque: or the store addresses are hoisted out of the band loop (24 VGPRs)
+            char *vo = (char *)(io.vis_optics + (size_t)hm * F);
+            const size_t VS = (size_t)A.nmodes * F * sizeof(double);
+            *(double *)(vo + boff) = hv0; *(double *)(vo + VS + boff) = hv1; *(double *)(vo + 2 * VS + boff) = hv2;
+        }
+        hm = -1;
+    };
     int cur = 0;
     for (int ib = 0; ib < nb; ++ib) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -474,6 +490,7 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
                 const int nspec = nsp[m];
                 const double *s_tbl = s_slice0 + cur * SLICE;
                 const size_t gsl = (size_t)m * nb + ib;
+                if (VIS && hm >= 0) hand_over_store();
                 {   // next slice: (m+1, ib) or (0, ib+1)
                     const int mn = (m + 1 < A.nmodes) ? m + 1 : 0;
                     const int ibn = (m + 1 < A.nmodes) ? ib : ib + 1;
@@ -495,19 +512,7 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
                 }
                 Wght wr, wi;
                 unit_weights<NTAB, LUT>(s_tbl, slices + gsl * SLICE, refr, refi, wr, wi);
-                double chm[NC];
-                if (VIS) {      // the hand-over stores need registers: keep only T1 of a mode and rebuild T2..T4 per unit (same
-                                // recurrence, same bits, six instructions) instead of spilling to scratch inside the band loop
-                                // (keeping T2 or T3 as well still spills)
-                    double x1 = cheb[m][1];
-                    asm volatile("" : "+v"(x1));    // opaque: or the rebuild is hoisted out of the band loop and T2..T4 are live again
-                    chm[0] = 1.0; chm[1] = x1;
-#pragma unroll
-                    for (int nc = 2; nc < NC; ++nc) chm[nc] = 2.0 * chm[1] * chm[nc - 1] - chm[nc - 2];
-                } else {
-#pragma unroll
-                    for (int nc = 0; nc < NC; ++nc) chm[nc] = cheb[m][nc];
-                }
+                const double *chm = cheb[m];
                 if (SW) {
                     double pext = interp_cheb(s_tbl, wr, wi, chm);
                     double pabs = interp_cheb(s_tbl + TBLP, wr, wi, chm);
@@ -524,12 +529,8 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
                     const double dopaer = pext * mass;
                     const double dw = (pext - pabs) * mass;
                     if (dopaer <= -1.e-10 || dopaer >= 30.0) bad = 1;
-                    if (VIS && ib == A.idx_sw_diag - 1 && live) {                 // hand-over to the diagnostics kernel (uniform test)
-                        // uniform plane pointer + 32-bit byte offset of the cell (recomputed from col, k: nothing extra stays live)
-                        const unsigned boff = ((unsigned)col * (unsigned)pver + (unsigned)(k - 1)) * 8u;
-                        char *vo = (char *)(io.vis_optics + (size_t)m * F);
-                        const size_t VS = (size_t)A.nmodes * F * sizeof(double);
-                        *(double *)(vo + boff) = pext; *(double *)(vo + VS + boff) = pabs; *(double *)(vo + 2 * VS + boff) = pasm;
+                    if (VIS && ib == A.idx_sw_diag - 1) {                         // hand-over to the diagnostics kernel (uniform test):
+                        hv0 = pext; hv1 = pabs; hv2 = pasm; hm = m;               // stored behind this unit's barrier, see above
                     }
                     a0 = a0 + dopaer;
                     a1 = a1 + dw;
@@ -560,6 +561,7 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
             }
         }
     }
+    if (VIS && hm >= 0) hand_over_store();              // the visible band was the last one
     if (live && bad && active) atomicOr(io.status + col, COLPHYS_STATUS_DOPAER_RANGE);
 }
 
