@@ -136,15 +136,26 @@ SPEC_TYPES = ["sulfate", "p-organic", "s-organic", "black-c", "dust", "seasalt"]
 NSPEC_M = (6, 4, 3, 2)
 
 
-def make_aero_props(seed: int = DEFAULT_SEED) -> dict:
-    """Per-mode / per-species property tables: smooth, seeded, physically plausible magnitudes."""
+# a MAM7-like variant for the tests: seven modes, up to eight species, modes that hold two species of one type (the species
+# partition of modal_aero_sw keeps the LAST one, modal_aer_opt.F90:780-829) and species of no partition type (-1)
+NSPEC_M7 = (6, 4, 7, 3, 3, 8, 2)
+SPECTYPE_M7 = ((0, 1, 2, 3, 4, 5, -1, -1), (0, 2, 5, 0, -1, -1, -1, -1), (4, 4, 0, 5, 3, 1, 4, -1), (4, 5, 0, -1, -1, -1, -1, -1),
+               (-1, 0, 5, -1, -1, -1, -1, -1), (3, 3, 1, 1, 2, 0, 5, 4), (0, -1, -1, -1, -1, -1, -1, -1))
+
+
+def make_aero_props(seed: int = DEFAULT_SEED, nspec_m=NSPEC_M, spectype=None) -> dict:
+    """Per-mode / per-species property tables: smooth, seeded, physically plausible magnitudes.
+    nspec_m / spectype: species counts per mode and their types [mode][species] (default: the MAM4-like set, types cycling)."""
     rng = np.random.Generator(np.random.PCG64(seed + 7))
-    nm, nsmax = len(NSPEC_M), max(NSPEC_M)
-    props = dict(nmodes=nm, nspec=np.array(NSPEC_M, dtype=np.int32), nspec_max=nsmax)
-    props["sigmag"] = np.array([1.8, 1.6, 1.8, 1.6])
+    nm, nsmax = len(nspec_m), max(nspec_m)
+    props = dict(nmodes=nm, nspec=np.array(nspec_m, dtype=np.int32), nspec_max=nsmax)
+    props["sigmag"] = np.array([1.8, 1.6] * nm)[:nm]
     props["specdens"] = rng.uniform(1000.0, 2600.0, (nm, nsmax))
     props["hygro"] = rng.uniform(1.0e-10, 1.2, (nm, nsmax))
-    props["spectype"] = np.array([[(l + m) % 6 for l in range(nsmax)] for m in range(nm)], dtype=np.int32)
+    if spectype is None:
+        props["spectype"] = np.array([[(l + m) % 6 for l in range(nsmax)] for m in range(nm)], dtype=np.int32)
+    else:
+        props["spectype"] = np.array([list(row)[:nsmax] for row in spectype], dtype=np.int32)
     props["specrefindex_sw"] = (rng.uniform(1.3, 1.9, (nm, nsmax, NSWBANDS))
                                 + 1j * rng.uniform(1.0e-9, 0.4, (nm, nsmax, NSWBANDS)))
     props["specrefindex_lw"] = (rng.uniform(1.2, 2.4, (nm, nsmax, NLWBANDS))

@@ -14,7 +14,7 @@ for name in cases.AERO_GOLDEN:
     g = cases.load_golden(name)
     pver = g["in_t"].shape[1]
     eng = ColumnPhysics(cases.default_params(pver), 0)
-    eng.aero_tables_set(synth.make_aero_props(int(g["seed"])), synth.PHYSCONST)
+    eng.aero_tables_set(cases.aero_props_from_golden(g), synth.PHYSCONST)
     d = eng.dev
     a = [d(g["in_" + k]) for k in ("pdeldry", "specmmr", "dgnumwet", "qaerwat")]
     sw = {k: v.cpu().numpy() for k, v in eng.modal_aero_sw(*a).items()}

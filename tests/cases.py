@@ -9,7 +9,7 @@ from cam_nor_physics_amd import abi, synth
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ZM_GOLDEN = ["zm_l32", "zm_l70", "zm_l32_cold", "zm_l32_pbl"]
-AERO_GOLDEN = ["aero_l32", "aero_l70"]
+AERO_GOLDEN = ["aero_l32", "aero_l70", "aero_m7"]
 PCOLS = 16
 
 
@@ -227,3 +227,11 @@ def swd_field_names(nmodes):
     for m in range(1, nmodes + 1):
         names += [f"BURDENdn{m:02d}", f"AODdn_mode{m}", f"AODdnDUST{m:02d}"]
     return list(abi.SWD_LEV_FIELDS), names
+
+
+def aero_props_from_golden(g):
+    """the property tables an optics fixture was generated with (tests/golden/make_golden.py aero_golden)"""
+    from cam_nor_physics_amd import synth
+    if "m7" in g and int(g["m7"]):
+        return synth.make_aero_props(int(g["seed"]), synth.NSPEC_M7, synth.SPECTYPE_M7)
+    return synth.make_aero_props(int(g["seed"]))

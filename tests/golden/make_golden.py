@@ -101,15 +101,15 @@ CASES = {
     "zm_l32_pbl": (32, 640, 32, 13, 20261007, {"namelist": {"parcel_pbl": 1, "no_deep_pbl": 1, "num_cin": 3}}),
 }
 
-def aero_golden(pver, ncol, seed):
+def aero_golden(pver, ncol, seed, m7=False):
     ref = RefOracle(PCOLS, pver)
-    props = synth.make_aero_props(seed)
+    props = synth.make_aero_props(seed, synth.NSPEC_M7, synth.SPECTYPE_M7) if m7 else synth.make_aero_props(seed)
     st = synth.make_state(ncol, pver, seed)
     aer = synth.make_aero_state(ncol, pver, props, seed)
     ref.aero_tables_set(props, synth.PHYSCONST)
     sw = ref.modal_aero_sw(st, aer)
     lw = ref.modal_aero_lw(st, aer)
-    g = {"seed": np.int64(seed), "in_pdeldry": st["pdeldry"], "in_pmid": st["pmid"], "in_t": st["t"]}
+    g = {"seed": np.int64(seed), "m7": np.int64(m7), "in_pdeldry": st["pdeldry"], "in_pmid": st["pmid"], "in_t": st["t"]}
     for k in ("specmmr", "dgnumwet", "qaerwat", "troplevchem"):
         g["in_" + k] = aer[k]
     for k, v in sw.items():
@@ -154,7 +154,8 @@ def geo_dse_golden(ncol, pver, seed):
     return g
 
 
-AERO_CASES = {"aero_l32": (32, 24, 20261004), "aero_l70": (70, 8, 20261005)}
+# aero_m7: seven modes (the kernels' more-than-four-modes path), duplicate and untyped species in the partition
+AERO_CASES = {"aero_l32": (32, 24, 20261004), "aero_l70": (70, 8, 20261005), "aero_m7": (32, 12, 20261008, True)}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(CASES) + list(AERO_CASES)

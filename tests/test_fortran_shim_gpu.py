@@ -80,7 +80,7 @@ def test_fortran_optics_caller_on_hip_engine_matches_reference_golden(name):
     g = cases.load_golden(name)
     n, pver = g["in_t"].shape
     f = shim(pver)
-    f.aero_tables_set(synth.make_aero_props(int(g["seed"])), synth.PHYSCONST)   # -> modal_aer_opt_init of the shim
+    f.aero_tables_set(cases.aero_props_from_golden(g), synth.PHYSCONST)   # -> modal_aer_opt_init of the shim
     st = {k: g["in_" + k] for k in ("pdeldry", "pmid", "t")}
     aer = {k: g["in_" + k] for k in ("specmmr", "dgnumwet", "qaerwat", "troplevchem")}
     sw = f.modal_aero_sw(st, aer)
@@ -91,7 +91,7 @@ def test_fortran_optics_caller_on_hip_engine_matches_reference_golden(name):
     # the history fields the shim's modal_aero_sw hands to outfld, captured by the same cam_history stand-in that captured
     # the reference's: "dn" set and day-only twins, night columns filled, SSAVISdn with the reference's night quirk
     dg = f.modal_aero_sw_diag(st, aer, g["in_nite"])
-    lev_names, col_names = cases.swd_field_names(4)
+    lev_names, col_names = cases.swd_field_names(len(cases.aero_props_from_golden(g)["nspec"]))
     for tag in ("", "_f"):
         for i, nm in enumerate(lev_names):
             assert_close(nm + tag, dg["lev" + tag][i], g["swd_lev" + tag][i])

@@ -246,7 +246,7 @@ def test_modal_aero_vs_reference_golden(name, family):
     g = cases.load_golden(name)
     pver = g["in_t"].shape[1]
     eng = engine(cases.default_params(pver))
-    eng.aero_tables_set(synth.make_aero_props(int(g["seed"])), synth.PHYSCONST)
+    eng.aero_tables_set(cases.aero_props_from_golden(g), synth.PHYSCONST)
     d = eng.dev
     a = (d(g["in_pdeldry"]), d(g["in_specmmr"]), d(g["in_dgnumwet"]), d(g["in_qaerwat"]))
     eng.aero_kernel_select(family, family)
@@ -292,7 +292,7 @@ def test_modal_aero_sw_diagnostics_vs_reference_golden(name, hand_over):
     g = cases.load_golden(name)
     pver = g["in_t"].shape[1]
     eng = engine(cases.default_params(pver))
-    eng.aero_tables_set(synth.make_aero_props(int(g["seed"])), synth.PHYSCONST)
+    eng.aero_tables_set(cases.aero_props_from_golden(g), synth.PHYSCONST)
     st = dict(pdeldry=g["in_pdeldry"], pmid=g["in_pmid"], t=g["in_t"])
     aer = {k: g["in_" + k] for k in ("specmmr", "dgnumwet", "qaerwat", "troplevchem")}
     dg = _swd_engine(eng, st, aer, hand_over)
