@@ -488,6 +488,56 @@ def test_table_interp_interval_search_scan_vs_lookup(sw, mode, band):
         assert np.allclose(at[fin], rt[fin], rtol=1e-14, atol=1e-300)
 
 
+def test_table_interp_lookup_on_random_grids():
+    """The lookup's host-side construction over many grid shapes -- linear, geometric over 1 to 12 decades, starting at 0 or
+    not, clustered -- either yields the scan's intervals exactly or is declined (then the kernels scan)."""
+    eng = engine(cases.default_params(32))
+    props = synth.make_aero_props(33)
+    rng = np.random.default_rng(1234)
+    made = declined = 0
+    for trial in range(40):
+        p = dict(props)
+        kind = trial % 5
+        def grid(n):
+            if kind == 0:
+                g = np.sort(rng.uniform(1.0, 3.0, n))
+            elif kind == 1:
+                g = np.geomspace(10.0 ** rng.uniform(-12, -2), 10.0 ** rng.uniform(-1, 1), n)
+            elif kind == 2:
+                g = np.concatenate([[0.0], np.geomspace(10.0 ** rng.uniform(-9, -3), rng.uniform(0.3, 2.0), n - 1)])
+            elif kind == 3:
+                g = np.cumsum(10.0 ** rng.uniform(-6, 0, n))                      # wildly uneven steps
+            else:
+                g = np.sort(rng.uniform(1.3, 1.3 + 10.0 ** rng.uniform(-9, -1), n))   # clustered: often declined
+            return g
+        p["refrtabsw"] = np.tile(grid(synth.PREFR), (props["nmodes"], synth.NSWBANDS, 1))
+        p["refitabsw"] = np.tile(grid(synth.PREFI), (props["nmodes"], synth.NSWBANDS, 1))
+        if not (np.all(np.diff(p["refrtabsw"][0, 0]) > 0) and np.all(np.diff(p["refitabsw"][0, 0]) > 0)):
+            continue
+        eng.aero_tables_set(p, synth.PHYSCONST)
+        for which, key, n in ((0, "refrtabsw", synth.PREFR), (1, "refitabsw", synth.PREFI)):
+            g = np.asarray(p[key][0, 0], dtype=np.float64)
+            x = np.concatenate([g, np.nextafter(g, np.inf), np.nextafter(g, -np.inf), 0.5 * (g[1:] + g[:-1]),
+                                np.array([0.0, 1e-300, 1e300]), rng.uniform(0.0, 2.0 * g[-1], 500),
+                                10.0 ** rng.uniform(np.log10(max(g[0], 1e-15)) - 1, np.log10(g[-1]) + 1, 500)])
+            a1, a2, at, avail = eng.aero_grid_probe(True, 0, 0, which, False, eng.dev(x))
+            if not avail:
+                declined += 1
+                break
+            b1, b2, bt, _ = eng.aero_grid_probe(True, 0, 0, which, True, eng.dev(x))
+            assert torch_equal(a1, b1) and torch_equal(a2, b2) and np.array_equal(at.cpu().numpy(), bt.cpu().numpy(), equal_nan=True), (trial, which)
+            r1, r2, _ = _table_interp_intervals(g, x)
+            assert np.array_equal(a1.cpu().numpy(), r1) and np.array_equal(a2.cpu().numpy(), r2), (trial, which)
+        else:
+            made += 1
+    assert made >= 15 and declined >= 1, (made, declined)
+    eng.aero_tables_set(props, synth.PHYSCONST)
+
+
+def torch_equal(a, b):
+    return bool((a == b).all().item())
+
+
 def test_modal_aero_tables_without_lookup_fall_back_to_the_scan(monkeypatch):
     """two real-index grid points one part in 1e12 apart share every bucket: no lookup for the SW tables, the kernels scan
     the grid; the LW tables keep theirs.  Then COLPHYS_AERO_NO_LUT forces the scan everywhere: bit-identical results."""
