@@ -395,8 +395,9 @@ int colphys_modal_aero_lw_chunks(int nchunks, int pcols, int pver, const int32_t
  *
  * A second output set of modal_aero_sw, computed from the same inputs AFTER colphys_modal_aero_sw_dev has filled
  * io->tauxar (the all-band / UV / near-IR totals are read from it: tauxar(:,k,isw) is the sum over modes of dopaer).
- * io->pmid, io->t and io->troplevchem are required here.  The visible band (idx_sw_diag) is re-evaluated per mode for
- * the quantities that need the per-mode pabs / pasm / palb and the species partition.
+ * io->pmid, io->t and io->troplevchem are required here.  The quantities that need the per-mode pabs / pasm / palb and the
+ * species partition take each mode's visible-band optics from io->vis_optics when the SW call was given that buffer (the
+ * fast path: no table is evaluated twice); with io->vis_optics NULL the visible band (idx_sw_diag) is re-evaluated per mode.
  *   lev  [COLPHYS_SWD_NLEV][ncol][pver]            level fields (1/m), zero above top_lev
  *   col  [COLPHYS_SWD_NCOL + 3*nmodes][ncol]       column fields; per mode m (0-based) at COLPHYS_SWD_NCOL + 3*m:
  *                                                   burden (BURDENdn<mm>), aodmode (AODdn_<mode>), dustaodmode (AODdnDUST<mm>)
