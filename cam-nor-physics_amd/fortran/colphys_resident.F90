@@ -88,11 +88,32 @@ module colphys_resident
        type(colphys_zm_conv_tend_2_io), intent(in) :: io
        type(c_ptr), value :: stream
      end function
+     ! the optics on resident data (include/colphys.h); colphys_modal_aero_io is declared in colphys_c_api
+     integer(c_int) function colphys_modal_aero_sw_dev(ncol, pver, io, stream) bind(C, name='colphys_modal_aero_sw_dev')
+       import
+       integer(c_int), value :: ncol, pver
+       type(colphys_modal_aero_io), intent(in) :: io
+       type(c_ptr), value :: stream
+     end function
+     integer(c_int) function colphys_modal_aero_lw_dev(ncol, pver, io, stream) bind(C, name='colphys_modal_aero_lw_dev')
+       import
+       integer(c_int), value :: ncol, pver
+       type(colphys_modal_aero_io), intent(in) :: io
+       type(c_ptr), value :: stream
+     end function
+     integer(c_int) function colphys_modal_aero_sw_diag_dev(ncol, pver, io, lev, col, stream) &
+          bind(C, name='colphys_modal_aero_sw_diag_dev')
+       import
+       integer(c_int), value :: ncol, pver
+       type(colphys_modal_aero_io), intent(in) :: io
+       type(c_ptr), value :: lev, col, stream
+     end function
   end interface
 
   public :: colphys_zm_conv_tend_dev, colphys_zm_conv_tend_2_dev
-  public :: colphys_alloc, colphys_alloc_int, colphys_release, colphys_upload, colphys_upload_multi, colphys_download, &
-            colphys_download_int, colphys_download_gathered_sets, colphys_sync
+  public :: colphys_modal_aero_sw_dev, colphys_modal_aero_lw_dev, colphys_modal_aero_sw_diag_dev
+  public :: colphys_alloc, colphys_alloc_int, colphys_release, colphys_upload, colphys_upload_multi, colphys_upload_int, &
+            colphys_download, colphys_download_int, colphys_download_gathered_sets, colphys_sync
 
 contains
 
@@ -164,6 +185,23 @@ contains
     end do
     call check(hipMemcpy(f%d, c_loc(tmp), int(size(tmp), c_size_t) * 8_c_size_t, hipMemcpyHostToDevice), 'hipMemcpy (upload)')
   end subroutine colphys_upload_multi
+
+  ! per-column integers, host (pcols, nchunks) -> device [nchunks*pcols]; padding rows shadow column 1 of their chunk
+  subroutine colphys_upload_int(f, host, pcols, nchunks, ncol)
+    type(colphys_field), intent(inout) :: f
+    integer, intent(in) :: pcols, nchunks, ncol(nchunks)
+    integer, intent(in) :: host(pcols, nchunks)
+    integer(c_int32_t), allocatable, target :: tmp(:)
+    integer :: c, i
+    if (.not. c_associated(f%d)) call colphys_alloc_int(f, nchunks*pcols)
+    allocate(tmp(nchunks*pcols))
+    do c = 1, nchunks
+       do i = 1, pcols
+          tmp((c-1)*pcols + i) = host(merge(i, 1, i <= ncol(c)), c)
+       end do
+    end do
+    call check(hipMemcpy(f%d, c_loc(tmp), int(size(tmp), c_size_t) * 4_c_size_t, hipMemcpyHostToDevice), 'hipMemcpy (upload)')
+  end subroutine colphys_upload_int
 
   ! device [nchunks*pcols][nlev] -> host (pcols, nlev, nchunks), the first nvalid(c) columns of each chunk
   subroutine colphys_download(f, host, pcols, nlev, nchunks, nvalid)

@@ -95,3 +95,90 @@ subroutine res_zm_conv_tend(nchunks, ncol, ztodt, dycore_kind, qmin,            
   call colphys_release(f_jt); call colphys_release(f_maxg); call colphys_release(f_ideep); call colphys_release(f_len)
   call colphys_release(f_status)
 end subroutine res_zm_conv_tend
+
+
+! The optics of a rank on resident data from Fortran: inputs of ALL chunks uploaded once (species mixing ratios in CAM's
+! (pcols,pver,species,chunk) order), modal_aero_sw with the hand-over buffer, its history diagnostics, modal_aero_lw; the band
+! outputs come back as (pcols, level, band, chunk) -- the device's [column][band][level] is exactly that per column.
+subroutine res_modal_aero(nchunks, ncol, nmodes, nspec_max, nsw, nlw, pdeldry, pmid, t, specmmr, dgnumwet, qaerwat, troplev, &
+     tauxar, wa, ga, fa, lwtau, dlev, dcol, nbad) bind(C, name='res_modal_aero')
+  use iso_c_binding
+  use ppgrid, only: pcols, pver, pverp
+  use colphys_c_api
+  use colphys_resident
+  implicit none
+  integer(c_int), value :: nchunks, nmodes, nspec_max, nsw, nlw
+  integer(c_int), intent(in) :: ncol(nchunks), troplev(pcols, nchunks)
+  real(c_double), intent(in) :: pdeldry(pcols,pver,nchunks), pmid(pcols,pver,nchunks), t(pcols,pver,nchunks)
+  real(c_double), intent(in) :: specmmr(pcols,pver,nspec_max*nmodes,nchunks), dgnumwet(pcols,pver,nmodes,nchunks), &
+                                qaerwat(pcols,pver,nmodes,nchunks)
+  real(c_double), intent(inout) :: tauxar(pcols,pverp*nsw,nchunks), wa(pcols,pverp*nsw,nchunks), ga(pcols,pverp*nsw,nchunks), &
+                                   fa(pcols,pverp*nsw,nchunks), lwtau(pcols,pver*nlw,nchunks)
+  real(c_double), intent(inout) :: dlev(pcols,pver,nchunks,5), dcol(pcols,1,nchunks,23+3*nmodes)
+  integer(c_int), intent(out) :: nbad
+
+  type(colphys_field) :: f_pd, f_pm, f_t, f_mmr, f_dg, f_qw, f_tl, f_out(5), f_vis, f_lev, f_col, f_st
+  type(colphys_modal_aero_io) :: io
+  integer :: nrows, i, rc, st(pcols, nchunks), f
+  type(colphys_field) :: view
+
+  nrows = nchunks * pcols
+  call colphys_upload(f_pd, pdeldry, pcols, pver, nchunks, ncol); call colphys_upload(f_pm, pmid, pcols, pver, nchunks, ncol)
+  call colphys_upload(f_t, t, pcols, pver, nchunks, ncol)
+  call colphys_upload_multi(f_mmr, specmmr, pcols, pver, nspec_max*nmodes, nchunks, ncol)
+  call colphys_upload_multi(f_dg, dgnumwet, pcols, pver, nmodes, nchunks, ncol)
+  call colphys_upload_multi(f_qw, qaerwat, pcols, pver, nmodes, nchunks, ncol)
+  call colphys_upload_int(f_tl, troplev, pcols, nchunks, ncol)
+  do i = 1, 4; call colphys_alloc(f_out(i), nrows, pverp*nsw); end do
+  call colphys_alloc(f_out(5), nrows, pver*nlw)
+  call colphys_alloc(f_vis, 3*nmodes*nrows, pver); call colphys_alloc(f_lev, 5*nrows, pver); call colphys_alloc(f_col, (23+3*nmodes)*nrows, 1)
+  call colphys_alloc_int(f_st, nrows)
+
+  io%pdeldry = f_pd%d; io%pmid = f_pm%d; io%t = f_t%d; io%specmmr = f_mmr%d; io%dgnumwet = f_dg%d; io%qaerwat = f_qw%d
+  io%troplevchem = f_tl%d; io%status = f_st%d
+  io%tauxar = f_out(1)%d; io%wa = f_out(2)%d; io%ga = f_out(3)%d; io%fa = f_out(4)%d; io%vis_optics = f_vis%d
+  nbad = -1
+  rc = colphys_modal_aero_sw_dev(nrows, pver, io, c_null_ptr);                       if (rc /= COLPHYS_OK) return
+  rc = colphys_modal_aero_sw_diag_dev(nrows, pver, io, f_lev%d, f_col%d, c_null_ptr); if (rc /= COLPHYS_OK) return
+  call colphys_sync()
+  st = 0
+  call colphys_download_int(f_st, st, pcols, nchunks, ncol)
+  nbad = count(st /= 0)
+  call colphys_download(f_out(1), tauxar, pcols, pverp*nsw, nchunks, ncol); call colphys_download(f_out(2), wa, pcols, pverp*nsw, nchunks, ncol)
+  call colphys_download(f_out(3), ga, pcols, pverp*nsw, nchunks, ncol);     call colphys_download(f_out(4), fa, pcols, pverp*nsw, nchunks, ncol)
+  ! the packed diagnostics are field-major on the device: one view per field
+  do f = 1, 5
+     view%d = c_ptr_plus(f_lev%d, int(f-1, c_size_t) * int(nrows, c_size_t) * int(pver, c_size_t) * 8_c_size_t)
+     view%nrows = nrows; view%nlev = pver
+     call colphys_download(view, dlev(:,:,:,f), pcols, pver, nchunks, ncol)
+  end do
+  do f = 1, 23 + 3*nmodes
+     view%d = c_ptr_plus(f_col%d, int(f-1, c_size_t) * int(nrows, c_size_t) * 8_c_size_t)
+     view%nrows = nrows; view%nlev = 1
+     call colphys_download(view, dcol(:,:,:,f), pcols, 1, nchunks, ncol)
+  end do
+  ! modal_aero_lw: the same resident inputs, its own output
+  io%tauxar = f_out(5)%d; io%wa = c_null_ptr; io%ga = c_null_ptr; io%fa = c_null_ptr; io%vis_optics = c_null_ptr
+  rc = colphys_modal_aero_lw_dev(nrows, pver, io, c_null_ptr)
+  if (rc /= COLPHYS_OK) then
+     nbad = -1
+     return
+  end if
+  call colphys_sync()
+  call colphys_download_int(f_st, st, pcols, nchunks, ncol)
+  nbad = nbad + count(st /= 0)
+  call colphys_download(f_out(5), lwtau, pcols, pver*nlw, nchunks, ncol)
+
+  call colphys_release(f_pd); call colphys_release(f_pm); call colphys_release(f_t); call colphys_release(f_mmr)
+  call colphys_release(f_dg); call colphys_release(f_qw); call colphys_release(f_tl); call colphys_release(f_vis)
+  call colphys_release(f_lev); call colphys_release(f_col); call colphys_release(f_st)
+  do i = 1, 5; call colphys_release(f_out(i)); end do
+
+contains
+  function c_ptr_plus(p, bytes) result(q)
+    type(c_ptr), intent(in) :: p
+    integer(c_size_t), intent(in) :: bytes
+    type(c_ptr) :: q
+    q = transfer(transfer(p, 0_c_intptr_t) + int(bytes, c_intptr_t), q)
+  end function c_ptr_plus
+end subroutine res_modal_aero

@@ -85,3 +85,68 @@ def test_fortran_whole_node_zm_conv_tend_matches_python_engine(ncol):
     # padding columns of the host arrays were never written (CAM's +inf / here NaN stays)
     if ncol % PCOLS:
         assert np.isnan(outs["ptend_s"][-1, :, ncol % PCOLS:]).all()
+
+
+def to_cam_multi(a, nchunks):
+    """[nf][ncol][nlev] -> C-ordered (nchunks, nf, nlev, pcols) = Fortran (pcols, nlev, nf, nchunks)"""
+    nf, ncol, nlev = a.shape
+    out = np.full((nchunks, nf, nlev, PCOLS), np.inf)
+    for c in range(nchunks):
+        n = min(PCOLS, ncol - c * PCOLS)
+        out[c, :, :, :n] = np.transpose(a[:, c * PCOLS:c * PCOLS + n, :], (0, 2, 1))
+    return out
+
+
+@pytest.mark.parametrize("ncol", [16 * 30, 16 * 30 - 5])
+def test_fortran_whole_node_optics_match_python_engine(ncol):
+    """modal_aero_sw (+ its history diagnostics through the hand-over buffer) and modal_aero_lw of all chunks of a rank from a
+    Fortran caller on resident data (tests/fortran/resident_driver.F90: res_modal_aero), bit for bit what the Python front
+    end gets from the same C ABI on the dense layout"""
+    from test_parity_gpu import engine
+    pver = 32
+    lib = C.CDLL(os.path.join(ROOT, "cam-nor-physics_amd", "_build", f"libcolphys_shim_p{PCOLS}_l{pver}.so"))
+    eng = engine(cases.default_params(pver))
+    props = synth.make_aero_props(91)
+    eng.aero_tables_set(props, synth.PHYSCONST)
+    st = synth.make_state(ncol, pver, 91)
+    aer = synth.make_aero_state(ncol, pver, props, 91)
+    nm, ns, nsw, nlw = props["nmodes"], props["nspec_max"], synth.NSWBANDS, synth.NLWBANDS
+    d = eng.dev
+    a = (d(st["pdeldry"]), d(aer["specmmr"]), d(aer["dgnumwet"]), d(aer["qaerwat"]))
+    vis = eng.empty(3, nm, ncol, pver)
+    sw = eng.modal_aero_sw(*a, vis=vis)
+    dg = eng.modal_aero_sw_diag(a[0], d(st["pmid"]), d(st["t"]), a[1], a[2], a[3], d(aer["troplevchem"].astype(np.int32)), sw["tauxar"], vis=vis)
+    lw = eng.modal_aero_lw(*a)
+    want = {k: sw[k].cpu().numpy() for k in ("tauxar", "wa", "ga", "fa")}
+    want_lw = lw["tauxar"].cpu().numpy()
+    want_lev, want_col = dg["lev"].cpu().numpy(), dg["col"].cpu().numpy()
+
+    nchunks = (ncol + PCOLS - 1) // PCOLS
+    ncols = np.array([min(PCOLS, ncol - c * PCOLS) for c in range(nchunks)], dtype=np.int32)
+    ins = [to_cam(st[k], nchunks) for k in ("pdeldry", "pmid", "t")]
+    mmr = to_cam_multi(aer["specmmr"].reshape(nm * ns, ncol, pver), nchunks)
+    dgn = to_cam_multi(aer["dgnumwet"], nchunks)
+    qw = to_cam_multi(aer["qaerwat"], nchunks)
+    tl = np.ones((nchunks, PCOLS), dtype=np.int32)
+    for c in range(nchunks):
+        tl[c, :ncols[c]] = aer["troplevchem"][c * PCOLS:c * PCOLS + ncols[c]]
+    outs = [np.full((nchunks, (pver + 1) * nsw, PCOLS), np.nan) for _ in range(4)]
+    lwtau = np.full((nchunks, pver * nlw, PCOLS), np.nan)
+    ncf = abi.SWD_NCOL + abi.SWD_NMODEF * nm
+    dlev = np.full((abi.SWD_NLEV, nchunks, pver, PCOLS), np.nan)
+    dcol = np.full((ncf, nchunks, 1, PCOLS), np.nan)
+    nbad = C.c_int(-7)
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    ip = lambda x: x.ctypes.data_as(C.POINTER(C.c_int32))
+    lib.res_modal_aero(C.c_int(nchunks), ip(ncols), C.c_int(nm), C.c_int(ns), C.c_int(nsw), C.c_int(nlw), *[dp(x) for x in ins],
+                       dp(mmr), dp(dgn), dp(qw), ip(tl), *[dp(x) for x in outs], dp(lwtau), dp(dlev), dp(dcol), C.byref(nbad))
+    assert nbad.value == 0
+    for k, o in zip(("tauxar", "wa", "ga", "fa"), outs):
+        assert np.array_equal(from_cam(o, ncol).reshape(ncol, nsw, pver + 1), want[k]), k
+    assert np.array_equal(from_cam(lwtau, ncol).reshape(ncol, nlw, pver), want_lw)
+    for f in range(abi.SWD_NLEV):
+        assert np.array_equal(from_cam(dlev[f], ncol), want_lev[f]), f
+    for f in range(ncf):
+        assert np.array_equal(from_cam(dcol[f], ncol)[:, 0], want_col[f]), f
+    if ncol % PCOLS:
+        assert np.isnan(outs[0][-1, :, ncol % PCOLS:]).all()
