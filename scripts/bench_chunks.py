@@ -59,3 +59,20 @@ for _ in range(n):
 dt = (time.perf_counter() - t0) / n
 print(f"colphys_zm_convr_chunks, {nch} chunks x {pcols} (48 602 columns x L32), host layout, PCIe-inclusive: "
       f"{dt * 1e3:.1f} ms per call = {ncol / dt / 1e6:.2f} M columns/s; deep columns {int(hout['lengath'].sum())}")
+
+# the legacy per-chunk entry: ONE chunk per call (what a chunk loop that calls the drop-in module per chunk does)
+io1 = abi.ZmConvrIO()
+one = {k: np.ascontiguousarray(v[:1]) for k, v in {**hin, **hout}.items() if k != "lengath"}
+one["lengath"] = np.zeros(1, dtype=np.int32)
+for k, v in one.items():
+    setattr(io1, k, abi.iptr(v) if v.dtype == np.int32 else abi.dptr(v))
+n1 = np.array([pcols], dtype=np.int32)
+for _ in range(5):
+    assert eng.lib.colphys_zm_convr_chunks(C.c_int(1), C.c_int(pcols), C.c_int(pver), abi.iptr(n1), C.c_double(args[9]), C.byref(io1)) == 0
+t0 = time.perf_counter()
+n = 200
+for _ in range(n):
+    eng.lib.colphys_zm_convr_chunks(C.c_int(1), C.c_int(pcols), C.c_int(pver), abi.iptr(n1), C.c_double(args[9]), C.byref(io1))
+dt1 = (time.perf_counter() - t0) / n
+print(f"colphys_zm_convr_chunks, ONE chunk of {pcols} columns per call: {dt1 * 1e6:.0f} us per call = {pcols / dt1 / 1e3:.1f} k columns/s "
+      f"({nch} such calls = {nch * dt1 * 1e3:.0f} ms per substep of a rank)")
