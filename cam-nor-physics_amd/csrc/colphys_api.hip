@@ -901,7 +901,36 @@ struct Stager {
     bool ok = true;                            // false once any copy / event call of this staging pass failed
     void chk(hipError_t e) { if (e != hipSuccess) ok = false; }
     std::function<void()> scatter_pending;     // scatter of the previous download, run while the next one is in flight
-    Stager(int nch, int pc, const int32_t *nc, void *hbase, void *dbase) : nchunks(nch), pcols(pc), ncol(nc), ncd(nch * pc), hc(hbase), dc(dbase) {}
+    // Few columns (the per-chunk legacy call: one chunk of pcols columns): the ~40 per-field copies are round trips that
+    // dominate the call, so the inputs -- packed back to back in the pinned arena at the SAME offsets as their device
+    // buffers -- go up in ONE copy (flush_in) and the outputs come down in ONE copy of the device range out<>() carved,
+    // scattered from there.  Many columns: per-field copies, each scatter overlapping the next download, as before.
+    bool batch;
+    size_t in_lo = 0, in_hi = 0, out_lo = 0, out_hi = 0;
+    char *h_out = nullptr;                     // pinned image of the device range [out_lo, out_hi)
+    Stager(int nch, int pc, const int32_t *nc, void *hbase, void *dbase)
+        : nchunks(nch), pcols(pc), ncol(nc), ncd(nch * pc), hc(hbase), dc(dbase), batch(nch * pc <= 512)
+    {
+        if (const char *e = getenv("COLPHYS_STAGE_BATCH")) batch = atoi(e) != 0;      // tests: either path at any size
+    }
+    // uploads the inputs packed so far (batch mode); call before the kernels are enqueued
+    void flush_in()
+    {
+        if (batch && in_hi > in_lo) chk(hipMemcpyAsync(dc.base + in_lo, hc.base + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, st));
+        in_lo = in_hi = 0;
+    }
+    // an input packed at h (pinned) for device buffer d: copy now, or remember the range when host and device offsets agree
+    void upload(void *d, const void *h, size_t bytes)
+    {
+        const size_t ho = (size_t)((const char *)h - hc.base), dof = (size_t)((char *)d - dc.base);
+        if (batch && ho == dof && (in_hi == in_lo || ho >= in_hi)) {
+            if (in_hi == in_lo) in_lo = ho;
+            in_hi = ho + bytes;                // the gap an alignment left between two fields is copied along (pinned, harmless)
+            return;
+        }
+        flush_in();
+        chk(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));
+    }
     ~Stager()
     {
         drain();
@@ -934,7 +963,7 @@ struct Stager {
                     }
                 }
         });
-        chk(hipMemcpyAsync(d, h, n * nf * sizeof(double), hipMemcpyHostToDevice, st));
+        upload(d, h, n * nf * sizeof(double));
         return d;
     }
     int32_t *in_i(const int32_t *src, int nlev)
@@ -946,16 +975,42 @@ struct Stager {
                 for (int i = 0; i < pcols; ++i)
                     for (int k = 0; k < nlev; ++k) h[((size_t)c * pcols + i) * nlev + k] = src[(size_t)c * pcols * nlev + (size_t)k * pcols + i];
         });
-        chk(hipMemcpyAsync(d, h, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        upload(d, h, n * sizeof(int32_t));
         return d;
     }
-    template <class T> T *out(int nlev) { return dc.take<T>((size_t)ncd * nlev); }
+    template <class T> T *out(int nlev)
+    {
+        flush_in();
+        T *d = dc.take<T>((size_t)ncd * nlev);
+        const size_t o = (size_t)((char *)d - dc.base);
+        if (out_hi == out_lo) out_lo = o;
+        out_hi = o + (size_t)ncd * nlev * sizeof(T);
+        return d;
+    }
 
     // download a device [col][nlev] field and scatter the first `valid(c)` columns of each chunk; the scatter of one
     // field runs while the download of the next is in flight (the last one is drained by the destructor)
     template <class T> void back(T *dst, const T *dev, int nlev, bool gathered, const int32_t *lengath)
     {
         const size_t n = (size_t)ncd * nlev;
+        const size_t dof = (size_t)((const char *)dev - dc.base);
+        if (batch && out_hi > out_lo && dof >= out_lo && dof + n * sizeof(T) <= out_hi) {
+            if (!h_out) {                              // first output asked for: the whole output range in one synchronous copy
+                h_out = hc.take<char>(out_hi - out_lo);
+                chk(hipMemcpy(h_out, dc.base + out_lo, out_hi - out_lo, hipMemcpyDeviceToHost));
+            }
+            if (!ok) return;
+            const T *h = (const T *)(h_out + (dof - out_lo));
+            for (int c = 0; c < nchunks; ++c) {
+                const int nv = gathered ? lengath[c] : ncol[c];
+                T *o = dst + (size_t)c * pcols * nlev;
+                for (int i = 0; i < nv; ++i) {
+                    const T *sp = h + ((size_t)c * pcols + i) * nlev;
+                    for (int k = 0; k < nlev; ++k) o[(size_t)k * pcols + i] = sp[k];
+                }
+            }
+            return;
+        }
         T *h = hc.take<T>(n);
         chk(hipMemcpyAsync(h, dev, n * sizeof(T), hipMemcpyDeviceToHost, st));
         drain();                                       // previous field: wait for ITS copy, scatter it
@@ -1015,6 +1070,7 @@ int colphys_geopotential_t_chunks(int nchunks, int pcols, int pver, const int32_
     // q: (pcols,pver,nq) per chunk in CAM; here the shim passes species-major (pcols,pver,nchunks,nq)
     double *d_q = s.in_multi(q, pver, nq);
     double *d_zi = s.out<double>(pverp), *d_zm = s.out<double>(pver);
+    s.flush_in();
     rc = colphys_geopotential_t_dev((int)ncd, pver, dycore_kind, nq, nspecies, d_piln, nullptr, d_pint, d_pmid, d_pdel,
                                     d_rpdel, d_t, d_q, d_rair, gravit, d_zvir, d_zi, d_zm, nullptr);
     if (rc) return rc;
@@ -1046,6 +1102,7 @@ int colphys_geopotential_dse_chunks(int nchunks, int pcols, int pver, const int3
     double *d_phis = s.in(phis, 1);
     double *d_q = s.in_multi(q, pver, nq);
     double *d_t = s.out<double>(pver), *d_zi = s.out<double>(pverp), *d_zm = s.out<double>(pver);
+    s.flush_in();
     rc = colphys_geopotential_dse_dev((int)ncd, pver, dycore_kind, nq, nspecies, d_piln, nullptr, d_pint, d_pmid, d_pdel, d_rpdel,
                                       d_dse, d_q, d_phis, d_rair, gravit, d_cpair, d_zvir, d_t, d_zi, d_zm, nullptr);
     if (rc) return rc;
@@ -1080,6 +1137,7 @@ int colphys_zm_convr_chunks(int nchunks, int pcols, int pver, const int32_t *nco
     d.jt = s.out<int32_t>(1); d.maxg = s.out<int32_t>(1); d.ideep = s.out<int32_t>(1); d.status = s.out<int32_t>(1);
     d.lengath = s.dc.take<int32_t>(nchunks);
     lk.unlock();
+    s.flush_in();
     rc = colphys_zm_convr_dev((int)ncd, pver, pcols, delt, &d, nullptr);
     lk.lock();
     if (rc) return rc;
@@ -1133,6 +1191,7 @@ int colphys_zm_conv_evap_chunks(int nchunks, int pcols, int pver, const int32_t 
     double **mid_d[] = {&d.tend_s, &d.tend_s_snwprd, &d.tend_s_snwevmlt, &d.tend_q, &d.ntprprd, &d.ntsnprd};
     for (auto pp : mid_d) *pp = s.out<double>(pver);
     d.flxprec = s.out<double>(pverp); d.flxsnow = s.out<double>(pverp); d.snow = s.out<double>(1);
+    s.flush_in();
     rc = colphys_zm_conv_evap_dev((int)ncd, pver, deltat, &d, nullptr);
     if (rc) return rc;
     const double *ms[] = {d.tend_s, d.tend_s_snwprd, d.tend_s_snwevmlt, d.tend_q, d.ntprprd, d.ntsnprd};
@@ -1169,6 +1228,7 @@ int colphys_momtran_chunks(int nchunks, int pcols, int pver, const int32_t *ncol
     for (auto &p : o3) p = s.dc.take<double>(2 * ncd * pver);
     d.dqdt = o3[0]; d.pguall = o3[1]; d.pgdall = o3[2]; d.icwu = o3[3]; d.icwd = o3[4];
     d.seten = s.out<double>(pver);
+    s.flush_in();
     rc = colphys_momtran_dev((int)ncd, pver, pcols, dt, &d, nullptr);
     if (rc) return rc;
     double *h3[] = {io->dqdt, io->pguall, io->pgdall, io->icwu, io->icwd};
@@ -1202,6 +1262,7 @@ int colphys_convtran_chunks(int nchunks, int pcols, int pver, const int32_t *nco
     d.lengath = dl;
     double *dq = s.dc.take<double>((size_t)ncnst * ncd * pver);
     d.dqdt = dq;
+    s.flush_in();
     rc = colphys_convtran_dev((int)ncd, pver, pcols, ncnst, dt, &d, nullptr);
     if (rc) return rc;
     for (int m = 1; m < ncnst; ++m)
@@ -1244,6 +1305,7 @@ static int aero_chunks(bool sw, int nchunks, int pcols, int pver, const int32_t 
     for (int f = 0; f < (sw ? 4 : 1); ++f) o[f] = s.dc.take<double>(ncd * nb * nlevout);
     d.tauxar = o[0]; d.wa = o[1]; d.ga = o[2]; d.fa = o[3];
     d.vis_optics = diag ? s.dc.take<double>(3 * (size_t)nm * ncd * pver) : nullptr;      // visible-band optics handed from SW to its diagnostics
+    s.flush_in();
     rc = sw ? colphys_modal_aero_sw_dev((int)ncd, pver, &d, nullptr) : colphys_modal_aero_lw_dev((int)ncd, pver, &d, nullptr);
     if (rc) return rc;
     double *dlev = nullptr, *dcol = nullptr;

@@ -652,9 +652,13 @@ def test_full_size_column_independence_and_gather(monkeypatch):
         assert np.all((o["prec"] >= 0)) and np.all(o["prec"][~np.isin(np.arange(ncol), src)] == 0)
 
 
-def test_chunk_entry_points_match_device_entry_points():
-    """The Fortran-facing (pcols,pver,nchunks) host-layout calls give the same numbers as the device calls."""
+@pytest.mark.parametrize("staging", ["batched", "per-field"])
+def test_chunk_entry_points_match_device_entry_points(staging, monkeypatch):
+    """The Fortran-facing (pcols,pver,nchunks) host-layout calls give the same numbers as the device calls -- with the
+    staging of a few-column call (inputs up / outputs down in one copy each) and with the per-field pipeline of a many-chunk
+    call (forced here at the same small size)."""
     import ctypes as C
+    monkeypatch.setenv("COLPHYS_STAGE_BATCH", "1" if staging == "batched" else "0")
     pver, pcols = 32, 16
     ncols = np.array([16, 16, 9, 16, 1], dtype=np.int32)       # ragged chunks, as ne30's last chunk
     nch = len(ncols)
