@@ -415,6 +415,37 @@ def test_modal_aero_sw_diagnostics_vs_c_oracle(pver, ncol, top_lev, hand_over):
         assert not got["lev"][:, :, :top_lev - 1].any()
 
 
+def test_modal_aero_full_size_properties():
+    """ne30 size (48 602 columns x L32), no oracle needed: (1) cells are independent -- permuting the columns permutes every
+    optics output bit for bit; (2) the optical depths are linear in the layer mass -- doubling pdeldry doubles tau, tau*w,
+    tau*w*g, tau*w*g*g and the LW tau exactly (a power of two commutes with every rounding on the way)."""
+    pver, ncol = 32, 48602
+    eng = engine(cases.default_params(pver))
+    props = synth.make_aero_props(4)
+    st = synth.make_state(ncol, pver, 4)
+    aer = synth.make_aero_state(ncol, pver, props, 4)
+    eng.aero_tables_set(props, synth.PHYSCONST)
+    d = eng.dev
+
+    def run(pdeldry, mmr, dgn, qw):
+        a = (d(pdeldry), d(mmr), d(dgn), d(qw))
+        sw = to_np(eng.modal_aero_sw(*a)); lw = to_np(eng.modal_aero_lw(*a))
+        return sw, lw
+
+    sw, lw = run(st["pdeldry"], aer["specmmr"], aer["dgnumwet"], aer["qaerwat"])
+    perm = np.random.default_rng(8).permutation(ncol)
+    swp, lwp = run(st["pdeldry"][perm], aer["specmmr"][:, :, perm], aer["dgnumwet"][:, perm], aer["qaerwat"][:, perm])
+    for k in ("tauxar", "wa", "ga", "fa"):
+        assert np.array_equal(swp[k], sw[k][perm]), k
+    assert np.array_equal(lwp["tauxar"], lw["tauxar"][perm])
+    sw2, lw2 = run(2.0 * st["pdeldry"], aer["specmmr"], aer["dgnumwet"], aer["qaerwat"])
+    for k in ("tauxar", "wa", "ga", "fa"):
+        want = 2.0 * sw[k]
+        want[:, :, 0] = sw[k][:, :, 0]                     # the zero'th layer holds presets, not aerosol (:639-642)
+        assert np.array_equal(sw2[k], want), k
+    assert np.array_equal(lw2["tauxar"], 2.0 * lw["tauxar"])
+
+
 def test_modal_aero_sw_diagnostics_identities_at_full_size():
     """ne30 size (48 602 columns): relations that hold whatever the inputs -- the column sums are the level sums of the level
     fields times mass / air density, the species optical depths add up to the visible one, stratospheric parts are parts"""
