@@ -54,8 +54,8 @@ def substep_bytes(L, sw_diag=True):
 
 PMC_KERNEL = {"geopotential_t": "geopotential_kernel", "zm_trigger": "zm_trigger_kernel", "zm_plume1": "zm_plume1_kernel",
               "zm_ascent2": "zm_ascent2_kernel", "zm_plume2": "zm_plume2_kernel",
-              "zm_conv_evap": "zm_conv_evap_kernel", "momtran": "momtran_wave_kernel", "modal_aero_sw": "modal_aero_reg_kernel<true, true>",
-              "modal_aero_lw": "modal_aero_kernel<false, true>"}
+              "zm_conv_evap": "zm_conv_evap_kernel", "momtran": "momtran_wave_kernel", "modal_aero_sw": "modal_aero_reg_kernel<true,",
+              "modal_aero_lw": "modal_aero_reg_kernel<false,", "modal_aero_sw_diag": "modal_aero_sw_diag_vis_kernel"}
 
 
 def pmc_of(kernel):
