@@ -323,7 +323,9 @@ def main():
         kern_ms = {k: v[0] for k, v in prof.items() if v[1] > 0}
         per_call = {"geopotential_t": BYTES["geopotential_t"](pver), "zm_trigger": BYTES["zm_convr"](pver),
                     "zm_conv_evap": BYTES["zm_conv_evap"](pver), "momtran": BYTES["momtran"](pver),
-                    "modal_aero_sw": BYTES["modal_aero_sw"](pver), "modal_aero_lw": BYTES["modal_aero_lw"](pver)}
+                    # with the diagnostics, modal_aero_sw also hands each mode's visible-band pext, pabs, pasm over (3 x nmodes doubles per cell)
+                    "modal_aero_sw": BYTES["modal_aero_sw"](pver) + (3 * 4 * pver * 8 if sw_diag else 0),
+                    "modal_aero_lw": BYTES["modal_aero_lw"](pver)}
         # share of one substep: geopotential_t and physics_update run three times
         share = {k: v * (3 if k in ("geopotential_t", "physics_update") else 1) for k, v in kern_ms.items()}
         dom = max((k for k in share if k in per_call), key=lambda k: share[k])
