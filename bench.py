@@ -114,8 +114,8 @@ def baseline_metric():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ncol", type=int, default=48602)
     ap.add_argument("--pver", type=int, default=32)
     ap.add_argument("--strong", action="store_true", help="split ONE --ncol slab over the ranks")
