@@ -683,6 +683,39 @@ def test_full_size_column_independence_and_gather(monkeypatch):
         assert np.all((o["prec"] >= 0)) and np.all(o["prec"][~np.isin(np.arange(ncol), src)] == 0)
 
 
+def test_full_size_water_budgets():
+    """48 602 columns x L32, the closed budgets the reference's formulation implies:
+    zm_convr -- precipitation is the column-integrated drying minus the detrained liquid (zm_conv.F90:1629-1638);
+    zm_conv_evap -- the precipitation flux at the surface is the column sum of the net production, what evaporates is
+    what moistens, and the heating is the latent heat of those two (zm_conv.F90:1943-1966)."""
+    ncol, pver = 48602, 32
+    eng = engine(cases.default_params(pver))
+    st = synth.make_state(ncol, pver, 78)
+    args = cases.zm_args_from_state(st, st["zi"], st["zm"])
+    o = run_zm(eng, args)
+    g = synth.PHYSCONST["gravit"]
+    col = -((o["qtnd"] + o["dlf"]) * st["pdel"]).sum(axis=1) / g / 1000.0
+    deep = o["prec"] > 0
+    assert deep.sum() > 0.03 * ncol
+    np.testing.assert_allclose(o["prec"][deep], col[deep], rtol=1e-9)
+    assert not col[~deep].any()
+    d = eng.dev
+    q1 = st["q"] + synth.ZTODT * o["qtnd"]                      # the state zm_conv_evap sees (zm_conv_intr.F90:739-764)
+    t1 = st["t"] + synth.ZTODT * o["heat"] / synth.PHYSCONST["cpair"]
+    e = to_np(eng.zm_conv_evap(d(t1), d(st["pmid"]), d(st["pdel"]), d(q1), d(st["landfrac"]), d(o["rprd"]), d(st["cld"]),
+                               synth.ZTODT, d(o["prec"].copy())))
+    for k, v in e.items():
+        assert np.isfinite(v).all(), k
+    net = (e["ntprprd"] * st["pdel"]).sum(axis=1) / g
+    np.testing.assert_allclose(e["flxprec"][:, pver], net, rtol=1e-9, atol=1e-14)    # up to the clamps at zero (:1947)
+    assert np.array_equal(e["prec"], e["flxprec"][:, pver] / 1000.0)
+    assert np.array_equal(e["snow"], e["flxsnow"][:, pver] / 1000.0)
+    assert (e["flxprec"] >= 0).all() and (e["flxsnow"] >= 0).all() and (e["tend_q"] >= 0).all()
+    evp = o["rprd"] - e["ntprprd"]                               # evaporated precipitation = the moistening
+    np.testing.assert_allclose(e["tend_q"], evp, rtol=1e-9, atol=1e-16)
+    assert (e["tend_q"] > 0).sum() > 1000
+
+
 @pytest.mark.parametrize("staging", ["batched", "per-field"])
 def test_chunk_entry_points_match_device_entry_points(staging, monkeypatch):
     """The Fortran-facing (pcols,pver,nchunks) host-layout calls give the same numbers as the device calls -- with the
