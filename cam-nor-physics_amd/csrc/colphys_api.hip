@@ -16,8 +16,12 @@
 
 namespace {
 
-std::mutex g_mu;
-std::string g_err;
+std::mutex g_mu;                  // the library's state: parameters, tables, grow-only device work arrays
+// Serialises the host-layout (*_chunks) calls from end to end: they share the staging arenas, the host thread pool and --
+// through the *_dev calls they make on the null stream -- the device work arrays.  A threaded chunk loop (the reference's
+// OpenMP loop over chunks, physpkg.F90:1147) may call them concurrently; the calls then run one after another.
+std::mutex g_stage_mu;
+thread_local std::string g_err;    // per calling thread: a concurrent caller's failure must not replace this thread's message
 bool g_init = false;
 int g_device = -1;
 ZmDev g_P;
@@ -140,6 +144,11 @@ struct ProfScope {
 int check_ready()
 {
     if (!g_init) return fail(COLPHYS_ERR_NOTINIT, "colphys_init has not been called");
+    // HIP's current device is per host thread: a thread other than the one that called colphys_init (an OpenMP worker of the
+    // reference's chunk loop) starts on device 0.  The calling thread is left on the engine's device.
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != g_device)
+        if (hipSetDevice(g_device) != hipSuccess) return fail(COLPHYS_ERR_HIP, "hipSetDevice(engine device) failed on the calling thread");
     return COLPHYS_OK;
 }
 int check_dims(int ncol, int pver)
@@ -201,6 +210,7 @@ void colphys_zm_params_defaults(colphys_zm_params *p)
 
 int colphys_init(int device, const colphys_zm_params *p)
 {
+    std::lock_guard<std::mutex> slk(g_stage_mu);        // not while a *_chunks call is in flight (order: stage, then state)
     std::lock_guard<std::mutex> lk(g_mu);
     if (!p) return fail(COLPHYS_ERR_ARG, "null params");
     int n = 0;
@@ -241,6 +251,7 @@ int colphys_init(int device, const colphys_zm_params *p)
 
 int colphys_finalize(void)
 {
+    std::lock_guard<std::mutex> slk(g_stage_mu);        // not while a *_chunks call is in flight (order: stage, then state)
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_init) {
         hipDeviceSynchronize();
@@ -388,7 +399,7 @@ int colphys_momtran_dev(int ncol, int pver, int pcols, double dt, const colphys_
     return rc ? fail(rc, "momtran launch failed") : COLPHYS_OK;
 }
 
-static std::mutex g_ct_mu;       // own lock: colphys_convtran_chunks calls colphys_convtran_dev with g_mu held
+static std::mutex g_ct_mu;       // the convtran row-list workspace
 static int convtran_ws(int ncol, int pcols, int **rows, int **count, int **il2g)
 {
     std::lock_guard<std::mutex> lk(g_ct_mu);
@@ -1057,7 +1068,7 @@ int colphys_geopotential_t_chunks(int nchunks, int pcols, int pver, const int32_
 {
     int rc;
     if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_stage_mu);
     const size_t ncd = (size_t)nchunks * pcols, pverp = pver + 1;
     const size_t bytes = 8 * ncd * (4 * pverp + (8 + (size_t)nq) * pver) + 64 * 256;
     if ((rc = stage_reserve(bytes, bytes))) return rc;
@@ -1089,7 +1100,7 @@ int colphys_geopotential_dse_chunks(int nchunks, int pcols, int pver, const int3
 {
     int rc;
     if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_stage_mu);
     const size_t ncd = (size_t)nchunks * pcols, pverp = pver + 1;
     const size_t bytes = 8 * ncd * (4 * pverp + (10 + (size_t)nq) * pver + 2) + 64 * 256;
     if ((rc = stage_reserve(bytes, bytes))) return rc;
@@ -1119,7 +1130,7 @@ int colphys_zm_convr_chunks(int nchunks, int pcols, int pver, const int32_t *nco
     int rc;
     if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
     if (!io) return fail(COLPHYS_ERR_ARG, "null io");
-    std::unique_lock<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_stage_mu);
     const size_t ncd = (size_t)nchunks * pcols, pverp = pver + 1;
     const size_t bytes = 8 * ncd * (4 * pverp + 22 * (size_t)pver + 16) + 4 * ncd * 8 + 128 * 256;
     if ((rc = stage_reserve(bytes, bytes))) return rc;
@@ -1136,10 +1147,8 @@ int colphys_zm_convr_chunks(int nchunks, int pcols, int pver, const int32_t *nco
     for (auto pp : col_d) *pp = s.out<double>(1);
     d.jt = s.out<int32_t>(1); d.maxg = s.out<int32_t>(1); d.ideep = s.out<int32_t>(1); d.status = s.out<int32_t>(1);
     d.lengath = s.dc.take<int32_t>(nchunks);
-    lk.unlock();
     s.flush_in();
     rc = colphys_zm_convr_dev((int)ncd, pver, pcols, delt, &d, nullptr);
-    lk.lock();
     if (rc) return rc;
     // padding columns must not appear in the gathered set: they are copies of column 1 of their chunk, so
     // they trigger exactly when it does; drop them on the host from ideep (ascending order is preserved)
@@ -1179,7 +1188,7 @@ int colphys_zm_conv_evap_chunks(int nchunks, int pcols, int pver, const int32_t 
     int rc;
     if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
     if (!io) return fail(COLPHYS_ERR_ARG, "null io");
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_stage_mu);
     const size_t ncd = (size_t)nchunks * pcols, pverp = pver + 1;
     const size_t bytes = 8 * ncd * (4 * pverp + 14 * (size_t)pver + 8) + 64 * 256;
     if ((rc = stage_reserve(bytes, bytes))) return rc;
@@ -1210,7 +1219,7 @@ int colphys_momtran_chunks(int nchunks, int pcols, int pver, const int32_t *ncol
     int rc;
     if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
     if (!io) return fail(COLPHYS_ERR_ARG, "null io");
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_stage_mu);
     const size_t ncd = (size_t)nchunks * pcols;
     const size_t bytes = 8 * ncd * (20 * (size_t)pver + 8) + 4 * ncd * 4 + 64 * 256;
     if ((rc = stage_reserve(bytes, bytes))) return rc;
@@ -1245,7 +1254,7 @@ int colphys_convtran_chunks(int nchunks, int pcols, int pver, const int32_t *nco
     int rc;
     if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
     if (!io || ncnst < 1) return fail(COLPHYS_ERR_ARG, "null io / bad ncnst");
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_stage_mu);
     const size_t ncd = (size_t)nchunks * pcols;
     const size_t bytes = 8 * ncd * ((3 * (size_t)ncnst + 8) * pver + 8) + 4 * ncd * 4 + 64 * 256;
     if ((rc = stage_reserve(2 * bytes, bytes))) return rc;
@@ -1279,7 +1288,7 @@ static int aero_chunks(bool sw, int nchunks, int pcols, int pver, const int32_t 
     if ((rc = check_ready()) || (rc = check_chunks(nchunks, pcols, ncol))) return rc;
     if (!g_aero_set) return fail(COLPHYS_ERR_NOTINIT, "colphys_aero_tables_set has not been called");
     if (!io) return fail(COLPHYS_ERR_ARG, "null io");
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_stage_mu);
     const size_t ncd = (size_t)nchunks * pcols, pverp = pver + 1;
     const int nm = g_A.nmodes, ns = g_A.nspec_max, nb = sw ? g_A.nswbands : g_A.nlwbands;
     const size_t nout = sw ? 4 * (size_t)nb * pverp : (size_t)nb * pver;

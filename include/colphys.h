@@ -53,6 +53,13 @@
  *   - No entry point retains caller pointers past its return (the *_dev ones: past stream completion).
  *   - There is no CPU fallback: every compute entry point fails with COLPHYS_ERR_NODEVICE when no HIP
  *     device is present.
+ *   - Threads.  The *_chunks entry points may be called concurrently from several host threads (the reference calls the path
+ *     from inside its OpenMP loop over chunks, physpkg.F90:1147): they share staging buffers and device work arrays, so the
+ *     library runs such calls one after another.  The *_dev entry points only enqueue; calls that use the library's grow-only
+ *     work arrays (zm_convr, zm_conv_tend, convtran / zm_conv_tend_2) must be ordered by the caller -- one stream, or events
+ *     between streams -- the others (geopotential, zm_conv_evap, momtran, the optics, the updates) are free of shared state.
+ *     colphys_init / colphys_aero_tables_set / colphys_finalize are not to overlap with compute calls.  Every call leaves
+ *     the calling thread on the engine's HIP device; colphys_last_error() is per calling thread.
  */
 #ifndef COLPHYS_H
 #define COLPHYS_H

@@ -773,6 +773,81 @@ def test_chunk_entry_points_match_device_entry_points(staging, monkeypatch):
             assert np.array_equal(hout[k][c, 0, :lg], o[k][:lg]), k
 
 
+def test_chunk_entry_is_safe_to_call_from_a_threaded_chunk_loop():
+    """The reference calls the path from inside an OpenMP loop over chunks (physpkg.F90:1147): concurrent per-chunk calls
+    from several host threads (ctypes drops the GIL during the call) give what the same calls give one after another."""
+    import ctypes as C
+    import threading
+    pver, pcols, nthr, rounds = 32, 16, 4, 3
+    eng = engine(cases.default_params(pver))
+
+    def make_call(seed, ncol):
+        st = synth.make_state(ncol, pver, seed)
+        a = cases.zm_args_from_state(st, st["zi"], st["zm"])
+        vals = dict(t=a[0], qh=a[1], pblh=a[2], zm=a[3], geos=a[4], zi=a[5], pap=a[6], paph=a[7], dpp=a[8], tpert=a[10], landfrac=a[11])
+
+        def chunk(x, nlev):
+            out = np.full((1, nlev, pcols), np.inf)
+            out[0, :, :ncol] = x.reshape(ncol, nlev).T
+            return out
+        hin = {k: chunk(vals[k], pver) for k in ("t", "qh", "pap", "dpp", "zm")}
+        hin.update({k: chunk(vals[k], pver + 1) for k in ("paph", "zi")})
+        hin.update({k: chunk(vals[k], 1) for k in ("geos", "pblh", "tpert", "landfrac")})
+
+        def run():
+            hout = {k: np.zeros((1, pver, pcols)) for k in abi.ZM_CONVR_OUT_MID}
+            hout.update({k: np.zeros((1, pver + 1, pcols)) for k in abi.ZM_CONVR_OUT_INT})
+            hout.update({k: np.zeros((1, 1, pcols)) for k in abi.ZM_CONVR_OUT_COL})
+            hout.update({k: np.zeros((1, 1, pcols), dtype=np.int32) for k in abi.ZM_CONVR_OUT_ICOL})
+            hout["lengath"] = np.zeros(1, dtype=np.int32)
+            io = abi.ZmConvrIO()
+            for k, v in {**hin, **hout}.items():
+                setattr(io, k, abi.iptr(v) if v.dtype == np.int32 else abi.dptr(v))
+            nc = np.array([ncol], dtype=np.int32)
+            rc = eng.lib.colphys_zm_convr_chunks(C.c_int(1), C.c_int(pcols), C.c_int(pver), abi.iptr(nc), C.c_double(a[9]), C.byref(io))
+            # the next call of the same thread's chunk iteration: another entry point through the same staging
+            ein = dict(t=hin["t"], pmid=hin["pap"], pdel=hin["dpp"], q=hin["qh"], prdprec=hout["rprd"], cldfrc=ecld,
+                       landfrac=hin["landfrac"], prec=hout["prec"].copy())
+            eout = {k: np.zeros((1, pver, pcols)) for k in ("tend_s", "tend_s_snwprd", "tend_s_snwevmlt", "tend_q", "ntprprd", "ntsnprd")}
+            eout.update({k: np.zeros((1, pver + 1, pcols)) for k in ("flxprec", "flxsnow")})
+            eout["snow"] = np.zeros((1, 1, pcols))
+            eio = abi.ZmConvEvapIO()
+            for k, v in {**ein, **eout}.items():
+                setattr(eio, k, abi.dptr(v))
+            rc2 = eng.lib.colphys_zm_conv_evap_chunks(C.c_int(1), C.c_int(pcols), C.c_int(pver), abi.iptr(nc), C.c_double(synth.ZTODT),
+                                                      C.byref(eio))
+            hout.update({"evap_" + k: v for k, v in eout.items()})
+            hout["evap_prec"] = ein["prec"]
+            return rc or rc2, hout
+        ecld = chunk(st["cld"], pver)
+        return run
+
+    calls = [make_call(500 + i, (16, 9, 16, 1)[i % 4]) for i in range(nthr)]
+    want = []
+    for run in calls:
+        rc, h = run()
+        assert rc == 0, eng.lib.colphys_last_error()
+        want.append(h)
+    assert sum(int(h["lengath"][0]) for h in want) > 0 and any(h["evap_tend_q"].any() for h in want)
+    got = [[None] * rounds for _ in range(nthr)]
+
+    def worker(i):
+        for r in range(rounds):
+            got[i][r] = calls[i]()
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(nthr)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+        assert not t.is_alive()
+    for i in range(nthr):
+        for r in range(rounds):
+            rc, h = got[i][r]
+            assert rc == 0
+            for k, v in h.items():
+                assert np.array_equal(v, want[i][k]), (i, r, k)
+
+
 def test_no_column_convects():
     """dry soundings: every chunk takes the reference's early return (lengath = 0, zm_conv.F90:917), outputs are the
     initial zeros / defaults, and the second-ascent / plume launches find an empty list"""
