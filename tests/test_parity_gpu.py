@@ -848,6 +848,95 @@ def test_chunk_entry_is_safe_to_call_from_a_threaded_chunk_loop():
                 assert np.array_equal(v, want[i][k]), (i, r, k)
 
 
+def test_endrun_conditions_are_reported_per_column():
+    """What the reference turns into endrun() comes back as per-column status bits, for exactly the columns the C restatement
+    flags, and leaves every other column's results untouched: a sounding that is not a number ends Brent's iteration
+    unconverged (zm_conv.F90:5401-5410, the `ientropy` abort a model blow-up ends in), an aerosol load beyond the sanity range
+    of the layer optical depth (modal_aer_opt.F90:997-1029 SW: 30; :1402-1437 LW: 20)."""
+    from c_oracle import COracle
+    pver, ncol = 32, 300
+    params = cases.default_params(pver)
+    eng = engine(params)
+    co = COracle(params)
+    st = synth.make_state(ncol, pver, 5)
+    args = list(cases.zm_args_from_state(st, st["zi"], st["zm"]))
+    clean = run_zm(eng, tuple(args))
+    assert not clean["status"].any()
+    t, q = args[0].copy(), args[1].copy()
+    t[7, :] = np.nan; t[50, 20] = np.nan; t[90, pver - 1] = np.nan; q[120, 25] = np.nan; t[299, :] = np.nan
+    bad = np.array([7, 50, 90, 120, 299])
+    args[0], args[1] = t, q
+    ref = co.zm_convr(*args)
+    o = run_zm(eng, tuple(args))
+    assert np.array_equal(o["status"], ref["status"])
+    assert (o["status"][[7, 299]] == 1).all() and o["status"].sum() == ref["status"].sum()       # COLPHYS_STATUS_BRENT_NOT_CONVERGED
+    ok = np.setdiff1d(np.arange(ncol), bad)
+    okc = np.setdiff1d(np.arange(ncol), np.concatenate([np.arange(b // 16 * 16, b // 16 * 16 + 16) for b in bad]))
+    for k in abi.ZM_CONVR_OUT_MID + abi.ZM_CONVR_OUT_INT + abi.ZM_CONVR_OUT_COL:
+        rows = okc if k in abi.ZM_CONVR_GATHERED else ok       # gathered rows of a chunk shift when a neighbour drops out
+        assert np.array_equal(o[k][rows], clean[k][rows]), k
+    # optics
+    props = synth.make_aero_props(9)
+    aer = synth.make_aero_state(ncol, pver, props, 9)
+    heavy = np.array([3, 64, 65, 298])
+    aer["specmmr"][:, :, heavy, 10:14] *= 3.0e6                 # specmmr [mode][species][col][lev]
+    eng.aero_tables_set(props, synth.PHYSCONST)
+    co.aero_tables_set(props, synth.PHYSCONST)
+    d = eng.dev
+    a = (d(st["pdeldry"]), d(aer["specmmr"]), d(aer["dgnumwet"]), d(aer["qaerwat"]))
+    sw, lw = to_np(eng.modal_aero_sw(*a)), to_np(eng.modal_aero_lw(*a))
+    sw_ref, lw_ref = co.modal_aero_sw(st, aer), co.modal_aero_lw(st, aer)
+    assert np.array_equal(sw["status"], sw_ref["status"]) and np.array_equal(lw["status"], lw_ref["status"])
+    assert set(np.flatnonzero(sw["status"])) == set(heavy) and (sw["status"][heavy] == 2).all()     # COLPHYS_STATUS_DOPAER_RANGE
+    assert set(np.flatnonzero(lw["status"])) <= set(heavy)
+    assert_close("modal_aero_sw.tauxar", sw["tauxar"], sw_ref["tauxar"])
+
+
+def test_argument_errors_are_refused_before_any_launch():
+    """zm_convi's aborts and the argument checks of the C ABI: an unsupported option or a malformed call returns its error code
+    with a message and leaves the engine as it was (the next correct call gives the same numbers as before)."""
+    import copy
+    import ctypes as C
+    from cam_nor_physics_amd.engine import ColphysError
+    pver, ncol = 32, 64
+    params = cases.default_params(pver)
+    eng = engine(params)
+    st = synth.make_state(ncol, pver, 21)
+    args = cases.zm_args_from_state(st, st["zi"], st["zm"])
+    before = run_zm(eng, args)
+    lib = eng.lib
+    for field, code in (("zmconv_microp", -5), ("zm_org", -5), ("cam3", -5)):      # COLPHYS_ERR_UNSUPPORTED (zm_conv.F90:3782, :75-78)
+        bad = copy.copy(params)
+        setattr(bad, field, 1)
+        assert lib.colphys_init(0, C.byref(bad)) == code, field
+        assert lib.colphys_last_error()
+    assert lib.colphys_init(99, C.byref(params)) == -1                              # no such device
+    bad = copy.copy(params)
+    bad.limcnv = pver                                                               # no level left under the convection top
+    assert lib.colphys_init(0, C.byref(bad)) == 0
+    with pytest.raises(ColphysError, match="limcnv"):
+        run_zm(eng, args)
+    assert lib.colphys_init(0, C.byref(params)) == 0
+    d = eng.dev
+    o = eng.alloc_zm_convr_out(ncol, pver, 16)
+    io = abi.ZmConvrIO()                                                            # every pointer null
+    assert lib.colphys_zm_convr_dev(C.c_int(ncol), C.c_int(pver), C.c_int(16), C.c_double(900.0), C.byref(io), None) == -1
+    assert b"null pointer" in lib.colphys_last_error()
+    assert lib.colphys_zm_convr_dev(C.c_int(ncol), C.c_int(pver), C.c_int(16), C.c_double(900.0), None, None) == -1
+    for n_, pv_, pc_ in ((0, pver, 16), (-3, pver, 16), (ncol, 3, 16), (ncol, 129, 16), (ncol, pver, 0), (ncol, pver, 5000)):
+        assert lib.colphys_zm_convr_dev(C.c_int(n_), C.c_int(pv_), C.c_int(pc_), C.c_double(900.0), C.byref(io), None) == -1, (n_, pv_, pc_)
+    nc = np.array([16, 17], dtype=np.int32)                                         # more columns than the chunk is wide
+    assert lib.colphys_zm_convr_chunks(C.c_int(2), C.c_int(16), C.c_int(pver), abi.iptr(nc), C.c_double(900.0), C.byref(io)) == -1
+    nc[1] = 0
+    assert lib.colphys_zm_convr_chunks(C.c_int(2), C.c_int(16), C.c_int(pver), abi.iptr(nc), C.c_double(900.0), C.byref(io)) == -1
+    assert lib.colphys_aero_kernel_select(7, 0) == -1
+    assert lib.colphys_profile_get(99, None, None) != 0
+    after = run_zm(eng, args)
+    for k in before:
+        assert np.array_equal(before[k], after[k]), k
+    del d, o
+
+
 def test_no_column_convects():
     """dry soundings: every chunk takes the reference's early return (lengath = 0, zm_conv.F90:917), outputs are the
     initial zeros / defaults, and the second-ascent / plume launches find an empty list"""
