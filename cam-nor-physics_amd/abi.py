@@ -12,6 +12,9 @@ COLPHYS_MAX_PVER = 128
 DYCORE_EUL, DYCORE_FV, DYCORE_SE = 0, 1, 2
 STATUS_BRENT_NOT_CONVERGED = 1
 STATUS_DOPAER_RANGE = 2
+STATUS_DOPAER_NEGATIVE = 4
+STATUS_BRENT_ENTHALPY = 8
+STATUS_COUNT_SHIFT = 8
 NCOEF, PREFR, PREFI = 5, 7, 10
 
 K_GEOPOTENTIAL, K_ZM_TRIGGER, K_ZM_PLUME, K_ZM_EVAP, K_MOMTRAN, K_AERO_SW, K_AERO_LW, K_UPDATE, K_CONVTRAN = range(9)

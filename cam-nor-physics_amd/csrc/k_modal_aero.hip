@@ -113,6 +113,16 @@ __device__ __forceinline__ void mix(int nspec, V vol, cptr_t ri, size_t stride, 
 // slice on the host; 0 for a degenerate interval and past the last point, which reproduces the reference's
 // `t = 0 when |dx| <= 1e-20`) for the two data-dependent reads.  t = (x-x1)*rdx differs from the reference's
 // (x-x1)/dx in the last bit at most.
+// The reference's sanity check of the layer optical depth (:997-1029, :1402-1437) as per-column status: the condition bits and,
+// above COLPHYS_STATUS_COUNT_SHIFT, the number of (mode, band, level) units outside the range -- what the reference adds to
+// nerr_dopaer and decides its abort on.
+__device__ __forceinline__ void status_report(int32_t *st, int bad, unsigned long long negm)
+{
+    const bool neg = (negm >> (threadIdx.x & 63)) & 1ull;
+    atomicOr(st, COLPHYS_STATUS_DOPAER_RANGE | (neg ? COLPHYS_STATUS_DOPAER_NEGATIVE : 0));
+    atomicAdd(st, bad << COLPHYS_STATUS_COUNT_SHIFT);
+}
+
 template <int N>
 __device__ __forceinline__ Wght calcwghts(cptr_t g, const double *s_g, const double *s_rdx, double x)
 {
@@ -263,7 +273,8 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
     for (int i = threadIdx.x; i < nbg * NOUT * NT; i += NT) s_acc[i] = 0.0;
 
     const double mass = io.pdeldry[cc] * A.rga;        // :644 / :1300
-    int bad = 0;
+    int bad = 0;                                       // units of this cell outside the sanity range of the optical depth (nerr_dopaer)
+    unsigned long long negm = 0;                       // lanes that met one <= -1e-10 (the reference halts below -1e-10; exactly -1e-10, which it only counts, is reported as negative too): wave-uniform, in SGPRs
     __syncthreads();
     int cur = 0;
 
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
                 pabs = fmin(pext, pabs);
                 const double dopaer = pext * mass;
                 const double dw = (pext - pabs) * mass;                 // dopaer*palb without the quotient (see the bands-outer kernel)
-                if (dopaer <= -1.e-10 || dopaer >= 30.0) bad = 1;       // :997
+                { const bool lo = dopaer <= -1.e-10, hi = dopaer >= 30.0; negm |= __ballot(lo); bad += (lo | hi) ? 1 : 0; }       // :997
                 if (VIS && ib == A.idx_sw_diag - 1 && live) {                     // hand-over to the diagnostics kernel
                     double *vo = io.vis_optics + (size_t)m * F + cc;
                     vo[0] = pext; vo[(size_t)A.nmodes * F] = pabs; vo[2 * (size_t)A.nmodes * F] = pasm;
@@ -351,7 +362,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
                 pabs = pabs * wetvol * A.rhoh2o;
                 pabs = fmax(0.0, pabs);
                 const double dopaer = pabs * mass;
-                if (dopaer <= -1.e-10 || dopaer >= 20.0) bad = 1;       // :1402
+                { const bool lo = dopaer <= -1.e-10, hi = dopaer >= 20.0; negm |= __ballot(lo); bad += (lo | hi) ? 1 : 0; }       // :1402
                 s_acc[(size_t)jb * NT + threadIdx.x] = s_acc[(size_t)jb * NT + threadIdx.x] + dopaer;   // :1441
             }
             __syncthreads();
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
             for (int jb = 0; jb < nbg; ++jb)
                 io.tauxar[((size_t)col * nb + (b0 + jb)) * L + (k - 1)] = active ? s_acc[(size_t)jb * NT + threadIdx.x] : 0.0;
         }
-        if (bad && active) atomicOr(io.status + col, COLPHYS_STATUS_DOPAER_RANGE);
+        if (bad && active) status_report(io.status + col, bad, negm);
     }
 }
 
@@ -420,7 +431,8 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
     slice_issue<SLICE>(slices, s_slice0);              // (mode 0, band 0)
 
     const double mass = io.pdeldry[cc] * A.rga;        // :644 / :1300
-    int bad = 0;
+    int bad = 0;                                       // units of this cell outside the sanity range of the optical depth (nerr_dopaer)
+    unsigned long long negm = 0;                       // lanes that met one <= -1e-10 (the reference halts below -1e-10; exactly -1e-10, which it only counts, is reported as negative too): wave-uniform, in SGPRs
 
     double cheb[NMMAX][NC], watervol[NMMAX], wetvol[NMMAX], wetinv[NMMAX], radsurf[NMMAX];
     // species counts: scalar loads, once.  (Read as A.nspec[m] inside the band loop they were VECTOR loads of a uniform
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
                     // below that both are < 1e-40 * mass.  A division sequence less per (band, mode) unit.
                     const double dopaer = pext * mass;
                     const double dw = (pext - pabs) * mass;
-                    if (dopaer <= -1.e-10 || dopaer >= 30.0) bad = 1;
+                    { const bool lo = dopaer <= -1.e-10, hi = dopaer >= 30.0; negm |= __ballot(lo); bad += (lo | hi) ? 1 : 0; }
                     if (VIS && ib == A.idx_sw_diag - 1) {                         // hand-over to the diagnostics kernel (uniform test):
                         hv0 = pext; hv1 = pabs; hv2 = pasm; hm = m;               // stored behind this unit's barrier, see above
                     }
@@ -541,7 +553,7 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
                     pabs = pabs * wetvol[m] * A.rhoh2o;
                     pabs = fmax(0.0, pabs);
                     const double dopaer = pabs * mass;
-                    if (dopaer <= -1.e-10 || dopaer >= 20.0) bad = 1;   // :1402
+                    { const bool lo = dopaer <= -1.e-10, hi = dopaer >= 20.0; negm |= __ballot(lo); bad += (lo | hi) ? 1 : 0; }   // :1402
                     a0 = a0 + dopaer;                                   // :1441
                 }
                 __syncthreads();
@@ -562,7 +574,7 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
         }
     }
     if (VIS && hm >= 0) hand_over_store();              // the visible band was the last one
-    if (live && bad && active) atomicOr(io.status + col, COLPHYS_STATUS_DOPAER_RANGE);
+    if (live && bad && active) status_report(io.status + col, bad, negm);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -202,7 +202,7 @@ __device__ BRENT_INLINE int invert_brent(const ZmDev &P, double s, double p, dou
     }
     T = b;
     qst = qb;                                  // = qsat_hPa(T, p) of :5399 / :5555, already evaluated at b
-    return converged ? 0 : COLPHYS_STATUS_BRENT_NOT_CONVERGED;
+    return converged ? 0 : (COLPHYS_STATUS_BRENT_NOT_CONVERGED | (KIND == 1 ? COLPHYS_STATUS_BRENT_ENTHALPY : 0));
 }
 
 // ------------------------------------------------------------------------------------------------------

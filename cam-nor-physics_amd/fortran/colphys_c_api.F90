@@ -8,6 +8,7 @@ module colphys_c_api
   integer(c_int), parameter :: COLPHYS_OK = 0
   integer(c_int), parameter :: COLPHYS_DYCORE_EUL = 0, COLPHYS_DYCORE_FV = 1, COLPHYS_DYCORE_SE = 2
   integer(c_int), parameter :: COLPHYS_STATUS_BRENT_NOT_CONVERGED = 1, COLPHYS_STATUS_DOPAER_RANGE = 2
+  integer(c_int), parameter :: COLPHYS_STATUS_DOPAER_NEGATIVE = 4, COLPHYS_STATUS_BRENT_ENTHALPY = 8, COLPHYS_STATUS_COUNT_SHIFT = 8
 
   type, bind(C) :: colphys_zm_params
     real(c_double) :: cpair, epsilo, gravit, latice, latvap, tmelt, rair, cpwv, cpliq, rh2o, cpvir, zvir

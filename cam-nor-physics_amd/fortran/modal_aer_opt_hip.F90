@@ -62,6 +62,8 @@ module AER_MODULE
 
   integer :: dgnumwet_idx = -1, qaerwat_idx = -1                    ! physics buffer indices (:63-64)
   integer :: nmodes_clim = 0, nspec_max = 0
+  integer, parameter :: nerrmax_dopaer = 1000                       ! :619, :1275
+  integer :: nerr_dopaer_sw = 0, nerr_dopaer_lw = 0                 ! :620 (modal_aero_sw's), :1276 (modal_aero_lw's)
   integer(c_int32_t), allocatable, target :: nspec_m(:)
 
 contains
@@ -287,18 +289,37 @@ contains
     end do
   end subroutine marshal_inputs
 
-  subroutine check_status(routine, lchnk, ncol, status, msg)
-    ! the reference aborts on an optical depth outside its sanity range (:997-1029, :1402-1437)
-    character(len=*), intent(in) :: routine, msg
+  subroutine check_status(subname, lchnk, ncol, status, nerr_dopaer, nerrmax)
+    ! The reference's sanity check of the layer optical depths (:997-1029 SW, :1402-1437 LW): every value outside the range is
+    ! logged and counted in nerr_dopaer (SAVEd in each routine, so counted over the run); the run halts on a negative value
+    ! -- a large one is a warning -- and, in modal_aero_lw only, once the count reaches nerrmax_dopaer.  The engine reports
+    ! per column what the reference tests per (mode, band, level): the count in the chunk is exact, the count quoted in the
+    ! halting message is the one at the end of the chunk's call, not at the first offending layer.
+    use string_utils, only: int2str
+    character(len=*), intent(in) :: subname
     integer, intent(in) :: lchnk, ncol
     integer(c_int32_t), intent(in) :: status(pcols)
+    integer, intent(inout) :: nerr_dopaer
+    integer, intent(in) :: nerrmax                  ! < 0: the count alone never halts (modal_aero_sw)
     integer :: i
+    logical :: negative
+    negative = .false.
     do i = 1, ncol
       if (iand(status(i), COLPHYS_STATUS_DOPAER_RANGE) /= 0) then
-        write(iulog,*) routine//': dopaer out of range in chunk', lchnk, ' column', i
-        call endrun(msg)
+        if (iand(status(i), COLPHYS_STATUS_DOPAER_NEGATIVE) /= 0) then
+          write(iulog,*) "ERROR: Negative aerosol optical depth in this layer."
+          negative = .true.
+        else
+          write(iulog,*) "WARNING: Aerosol optical depth is unreasonably high in this layer."
+        end if
+        write(iulog,*) subname//': lchnk=', lchnk, ' column=', i, ' layers out of range=', ishft(status(i), -COLPHYS_STATUS_COUNT_SHIFT)
+        nerr_dopaer = nerr_dopaer + ishft(status(i), -COLPHYS_STATUS_COUNT_SHIFT)
       end if
     end do
+    if (negative .or. (nerrmax >= 0 .and. nerr_dopaer >= nerrmax)) then
+      write(iulog,*) '*** halting in ', subname, ' after nerr_dopaer =', nerr_dopaer
+      call endrun('*** halting in '//subname//' after nerr_dopaer = '//int2str(nerr_dopaer))
+    end if
   end subroutine check_status
 
   !---------------------------------------------------------------------------------------------------------
@@ -352,7 +373,7 @@ contains
     ncol_c(1) = ncol
     rc = colphys_modal_aero_sw_diag_chunks(1, pcols, pver, ncol_c, io, c_loc(dlev), c_loc(dcol))
     if (rc /= COLPHYS_OK) call endrun('modal_aero_sw (colphys): '//trim(colphys_error_message()))
-    call check_status('modal_aero_sw', lchnk, ncol, status, 'exit from modal_aero_sw')
+    call check_status('modal_aero_sw', lchnk, ncol, status, nerr_dopaer_sw, -1)
 
     ! ---- history output, as the reference orders it ---------------------------------------------------------
     do m = 1, nmodes_clim                                                           ! :1046-1074
@@ -431,7 +452,7 @@ contains
     ncol_c(1) = state%ncol
     rc = colphys_modal_aero_lw_chunks(1, pcols, pver, ncol_c, io)
     if (rc /= COLPHYS_OK) call endrun('modal_aero_lw (colphys): '//trim(colphys_error_message()))
-    call check_status('modal_aero_lw', state%lchnk, state%ncol, status, 'exit from modal_aero_lw')
+    call check_status('modal_aero_lw', state%lchnk, state%ncol, status, nerr_dopaer_lw, nerrmax_dopaer)
   end subroutine modal_aero_lw
 
 end module AER_MODULE

@@ -191,7 +191,13 @@ subroutine zm_convr(lchnk   ,ncol    , &
    lengath = lengath_c(1)
    do i = 1, ncol                                                       ! zm_conv.F90:5401-5410, 5557-5566
       if (iand(status_c(i), COLPHYS_STATUS_BRENT_NOT_CONVERGED) /= 0) then
-         write(iulog,*) '*** ZM_CONV: IENTROPY/IENTHALPY: Failed and about to exit, lchnk,icol= ', lchnk, i
+         ! the inversions of a column run ienthalpy first (parcel_dilute's first loop, :5102, :5129), so that is the one the
+         ! reference would have stopped in when both kinds failed
+         if (iand(status_c(i), COLPHYS_STATUS_BRENT_ENTHALPY) /= 0) then
+            write(iulog,*) '*** ZM_CONV: IENTHALPY: Failed and about to exit, lchnk,icol= ', lchnk, i
+            call endrun('**** ZM_CONV IENTHALPY: Tmix did not converge ****')
+         end if
+         write(iulog,*) '*** ZM_CONV: IENTROPY: Failed and about to exit, lchnk,icol= ', lchnk, i
          call endrun('**** ZM_CONV IENTROPY: Tmix did not converge ****')
       end if
    end do

@@ -48,8 +48,12 @@
  *     zm_conv_intr.F90:700-706,1006-1017).
  *   - Return value 0 = ok, < 0 = argument/runtime error (colphys_last_error()), and the per-column
  *     status[] array carries the conditions the reference turns into endrun():
- *       bit 0 (1): ientropy/ienthalpy did not converge  (zm_conv.F90:5401-5410, 5557-5566)
- *       bit 1 (2): aerosol optical depth out of range    (modal_aer_opt.F90:997-1029, 1402-1437)
+ *       bit 0 (1): ientropy/ienthalpy did not converge  (zm_conv.F90:5401-5410, 5557-5566); bit 3 (8) with it when an
+ *                  ienthalpy inversion was among them (the reference meets those first and names the routine in its message)
+ *       bit 1 (2): aerosol optical depth of a layer outside its sanity range (modal_aer_opt.F90:997-1029 SW, 1402-1437 LW);
+ *                  bit 2 (4) with it when one was negative (< -1e-10); status >> 8 counts the (mode, band, level) units of the
+ *                  column outside the range.  The reference only WARNS about a large value and adds it to nerr_dopaer; it halts
+ *                  on a negative one (SW, LW) and once nerr_dopaer reaches 1000 (LW) -- the shim's decision, from these fields.
  *   - No entry point retains caller pointers past its return (the *_dev ones: past stream completion).
  *   - There is no CPU fallback: every compute entry point fails with COLPHYS_ERR_NODEVICE when no HIP
  *     device is present.
@@ -81,6 +85,9 @@ extern "C" {
 
 #define COLPHYS_STATUS_BRENT_NOT_CONVERGED 1
 #define COLPHYS_STATUS_DOPAER_RANGE        2
+#define COLPHYS_STATUS_DOPAER_NEGATIVE     4      /* set with DOPAER_RANGE: an optical depth < -1e-10 (the reference halts on these) */
+#define COLPHYS_STATUS_BRENT_ENTHALPY      8      /* set with BRENT_NOT_CONVERGED: an ienthalpy inversion failed (they come first) */
+#define COLPHYS_STATUS_COUNT_SHIFT         8      /* status >> 8: number of out-of-range optical depths of the column (nerr_dopaer) */
 
 #define COLPHYS_MAX_PVER 128
 

@@ -135,7 +135,7 @@ double oracle_enthalpy(double TK, double p, double qtot, double z)
 }
 
 /* ientropy :5304-5414 / ienthalpy :5460-5570 -- Brent's method; kind 0 = entropy, 1 = enthalpy.
- * Returns 0 if converged. */
+ * Returns 0 if converged, else the status bits of include/colphys.h (which inversion failed). */
 static int invert_brent(int kind, double s, double p, double z, double qt, double *T, double *qst, double Tfg)
 {
 #define FEVAL(x) ((kind ? oracle_enthalpy((x), p, qt, z) : oracle_entropy((x), p, qt)) - s)
@@ -193,7 +193,7 @@ static int invert_brent(int kind, double s, double p, double z, double qt, doubl
     *T = b;
     double est;
     qsat_hPa(*T, p, &est, qst);
-    return converged ? 0 : 1;
+    return converged ? 0 : (COLPHYS_STATUS_BRENT_NOT_CONVERGED | (kind ? COLPHYS_STATUS_BRENT_ENTHALPY : 0));
 #undef FEVAL
 }
 
@@ -932,7 +932,7 @@ static int zm_convr_column(int pver, double delt, const col_view *c, gath_out *g
     b.status = 0;
     buoyan_dilute(pver, msg, q, c->t, p, z, pf, pblt, c->zi, zs, c->tpert, dmpdz, 0.0, &b);   /* :886 */
     *c->cape = b.cape;
-    *c->status |= b.status ? COLPHYS_STATUS_BRENT_NOT_CONVERGED : 0;
+    *c->status |= b.status;
 
     if (!(b.cape > P.capelmt && b.cin < b.cape * P.cin_threshd)) return 0;      /* :908-917 */
 
@@ -968,7 +968,7 @@ static int zm_convr_column(int pver, double delt, const col_view *c, gath_out *g
         b.status = 0;
         buoyan_dilute(pver, msg, q, c->t, p, z, pf, pblt, c->zi, zs, c->tpert, dmpdz, cin_prev, &b);   /* :1080 */
         *c->cape = b.cape;
-        *c->status |= b.status ? COLPHYS_STATUS_BRENT_NOT_CONVERGED : 0;
+        *c->status |= b.status;
     }
     if (!(b.cape > P.capelmt && b.cin < b.cape * P.cin_threshd)) return 0;      /* :1099-1107 retrigger */
 

@@ -133,7 +133,7 @@ void oracle_modal_aero_sw(int ncol, int pver, const colphys_modal_aero_io *io)
                     pabs = fmin(pext, pabs);
                     palb = 1.0 - pabs / fmax(pext, 1.e-40);
                     dopaer = pext * mass;
-                    if (dopaer <= -1.e-10 || dopaer >= 30.0) io->status[i] |= COLPHYS_STATUS_DOPAER_RANGE;   /* :997 */
+                    if (dopaer <= -1.e-10 || dopaer >= 30.0) io->status[i] = (io->status[i] | COLPHYS_STATUS_DOPAER_RANGE | (dopaer < -1.e-10 ? COLPHYS_STATUS_DOPAER_NEGATIVE : 0)) + (1 << COLPHYS_STATUS_COUNT_SHIFT);   /* :997 */
                     tau[k] = tau[k] + dopaer;                                    /* :1032-1037 */
                     wa[k] = wa[k] + dopaer * palb;
                     ga[k] = ga[k] + dopaer * palb * pasm;
@@ -333,7 +333,7 @@ void oracle_modal_aero_lw(int ncol, int pver, const colphys_modal_aero_io *io)
                     pabs = pabs * wetvol * T.rhoh2o;
                     pabs = fmax(0.0, pabs);
                     double dopaer = pabs * mass;
-                    if (dopaer <= -1.e-10 || dopaer >= 20.0) io->status[i] |= COLPHYS_STATUS_DOPAER_RANGE;   /* :1402 */
+                    if (dopaer <= -1.e-10 || dopaer >= 20.0) io->status[i] = (io->status[i] | COLPHYS_STATUS_DOPAER_RANGE | (dopaer < -1.e-10 ? COLPHYS_STATUS_DOPAER_NEGATIVE : 0)) + (1 << COLPHYS_STATUS_COUNT_SHIFT);   /* :1402 */
                     tau[k] = tau[k] + dopaer;                                    /* :1441 */
                 }
             }

@@ -869,7 +869,8 @@ def test_endrun_conditions_are_reported_per_column():
     ref = co.zm_convr(*args)
     o = run_zm(eng, tuple(args))
     assert np.array_equal(o["status"], ref["status"])
-    assert (o["status"][[7, 299]] == 1).all() and o["status"].sum() == ref["status"].sum()       # COLPHYS_STATUS_BRENT_NOT_CONVERGED
+    # a sounding without a number anywhere fails in the first inversion the ascent makes, an ienthalpy (zm_conv.F90:5102)
+    assert (o["status"][[7, 299]] == abi.STATUS_BRENT_NOT_CONVERGED | abi.STATUS_BRENT_ENTHALPY).all()
     ok = np.setdiff1d(np.arange(ncol), bad)
     okc = np.setdiff1d(np.arange(ncol), np.concatenate([np.arange(b // 16 * 16, b // 16 * 16 + 16) for b in bad]))
     for k in abi.ZM_CONVR_OUT_MID + abi.ZM_CONVR_OUT_INT + abi.ZM_CONVR_OUT_COL:
@@ -880,6 +881,9 @@ def test_endrun_conditions_are_reported_per_column():
     aer = synth.make_aero_state(ncol, pver, props, 9)
     heavy = np.array([3, 64, 65, 298])
     aer["specmmr"][:, :, heavy, 10:14] *= 3.0e6                 # specmmr [mode][species][col][lev]
+    pdeldry = st["pdeldry"].copy()
+    pdeldry[17, 5] *= -1.0e4                                    # a negative layer mass: negative optical depths, SW and LW
+    st = dict(st, pdeldry=pdeldry)
     eng.aero_tables_set(props, synth.PHYSCONST)
     co.aero_tables_set(props, synth.PHYSCONST)
     d = eng.dev
@@ -887,8 +891,13 @@ def test_endrun_conditions_are_reported_per_column():
     sw, lw = to_np(eng.modal_aero_sw(*a)), to_np(eng.modal_aero_lw(*a))
     sw_ref, lw_ref = co.modal_aero_sw(st, aer), co.modal_aero_lw(st, aer)
     assert np.array_equal(sw["status"], sw_ref["status"]) and np.array_equal(lw["status"], lw_ref["status"])
-    assert set(np.flatnonzero(sw["status"])) == set(heavy) and (sw["status"][heavy] == 2).all()     # COLPHYS_STATUS_DOPAER_RANGE
-    assert set(np.flatnonzero(lw["status"])) <= set(heavy)
+    bits, count = sw["status"] & 0xff, sw["status"] >> abi.STATUS_COUNT_SHIFT
+    assert set(np.flatnonzero(bits)) == set(heavy) | {17}
+    assert (bits[heavy] == abi.STATUS_DOPAER_RANGE).all()                                    # large: the reference warns and counts
+    assert bits[17] == abi.STATUS_DOPAER_RANGE | abi.STATUS_DOPAER_NEGATIVE                  # negative: it halts
+    assert (count[heavy] >= 4).all() and count[17] == 4 * synth.NSWBANDS and (count[bits == 0] == 0).all()
+    lbits = lw["status"] & 0xff
+    assert lbits[17] == abi.STATUS_DOPAER_RANGE | abi.STATUS_DOPAER_NEGATIVE and (lbits[heavy] == abi.STATUS_DOPAER_RANGE).all()
     assert_close("modal_aero_sw.tauxar", sw["tauxar"], sw_ref["tauxar"])
 
 
