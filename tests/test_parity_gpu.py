@@ -394,6 +394,38 @@ def test_modal_aero_vs_c_oracle(pver, ncol, top_lev):
         assert sw["tauxar"][:, :, top_lev:].all()
 
 
+@pytest.mark.parametrize("family", ["bands-outer", "grouped"])
+@pytest.mark.parametrize("nspec_m", [(5,), (1,), (2, 6), (8, 1, 3), (1, 1, 1, 1), (3, 2, 4, 1, 5), (2,) * 9])
+def test_modal_aero_mode_and_species_counts_vs_c_oracle(nspec_m, family):
+    """one mode, one species, the four-mode limit of the bands-outer kernels and what lies beyond it (five and nine modes take
+    the grouped kernels whatever is asked for), up to eight species per mode: radiative outputs and history diagnostics"""
+    from c_oracle import COracle
+    pver, ncol = 32, 333
+    params = cases.default_params(pver)
+    eng = engine(params)
+    co = COracle(params)
+    props = synth.make_aero_props(31, nspec_m=nspec_m)
+    st = synth.make_state(ncol, pver, 31)
+    aer = synth.make_aero_state(ncol, pver, props, 31)
+    eng.aero_tables_set(props, synth.PHYSCONST)
+    co.aero_tables_set(props, synth.PHYSCONST)
+    eng.aero_kernel_select(family, family)
+    try:
+        d = eng.dev
+        a = (d(st["pdeldry"]), d(aer["specmmr"]), d(aer["dgnumwet"]), d(aer["qaerwat"]))
+        sw, sw_ref = to_np(eng.modal_aero_sw(*a)), co.modal_aero_sw(st, aer)
+        lw, lw_ref = to_np(eng.modal_aero_lw(*a)), co.modal_aero_lw(st, aer)
+        for k in ("tauxar", "wa", "ga", "fa"):
+            assert_close("modal_aero_sw." + k, sw[k], sw_ref[k])
+        assert_close("modal_aero_lw.tauxar", lw["tauxar"], lw_ref["tauxar"])
+        assert not sw["status"].any() and not lw["status"].any()
+        want = co.modal_aero_sw_diag(st, aer)
+        for hand_over in (True, False):
+            _assert_swd(_swd_engine(eng, st, aer, hand_over), want["lev"], want["col"], len(nspec_m))
+    finally:
+        eng.aero_kernel_select("auto", "auto")
+
+
 @pytest.mark.parametrize("hand_over", [True, False])
 @pytest.mark.parametrize("pver,ncol,top_lev", [(32, 701, 1), (32, 203, 4), (70, 100, 1), (26, 37, 2), (128, 130, 1), (4, 77, 1)])
 def test_modal_aero_sw_diagnostics_vs_c_oracle(pver, ncol, top_lev, hand_over):
