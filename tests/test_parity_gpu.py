@@ -5,6 +5,8 @@
       chunk-width independence, gathered-layout consistency.
 Tolerance 1e-10 relative (tests/util.py); integer outputs identical.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -342,6 +344,22 @@ def test_full_chain_vs_c_oracle(pver, ncol, seed):
                           *[d(ref[k]) for k in ("jt", "maxg", "ideep", "lengath")], dt))
     for k, v in m.items():
         assert_close("momtran." + k, v, m_ref[k])
+
+
+def test_namelist_and_sounding_regimes_vs_c_oracle():
+    """scripts/stress_parity.py, ten seeded regimes: PBL-mixed parcels, no_deep_pbl, 1..5 CIN regions, tiedke_add, capelmt, tau,
+    dmpdz, momentum coefficients, autoconversion and evaporation coefficients, cold / hot / dry / very moist soundings, odd
+    level counts -- zm_convr, zm_conv_evap and momtran against the C restatement at 1e-10, gathered sets identical"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STRESS_REGIMES="10", STRESS_SEED="7")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_parity.py")], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    last = [ln for ln in r.stdout.splitlines() if ln.startswith("worst over")]
+    assert last and float(last[-1].split()[-1]) < 1e-10, r.stdout[-2000:]
+    assert sum(ln.startswith("regime") for ln in r.stdout.splitlines()) == 10, r.stdout[-2000:]
 
 
 def test_evap_snow_paths_vs_c_oracle():
