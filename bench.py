@@ -323,8 +323,10 @@ def main():
         kern_ms = {k: v[0] for k, v in prof.items() if v[1] > 0}
         per_call = {"geopotential_t": BYTES["geopotential_t"](pver), "zm_trigger": BYTES["zm_convr"](pver),
                     "zm_conv_evap": BYTES["zm_conv_evap"](pver), "momtran": BYTES["momtran"](pver),
-                    # with the diagnostics, modal_aero_sw also hands each mode's visible-band pext, pabs, pasm over (3 x nmodes doubles per cell)
-                    "modal_aero_sw": BYTES["modal_aero_sw"](pver) + (3 * 4 * pver * 8 if sw_diag else 0),
+                    # SURVEY.md 8d's figure.  With the diagnostics the launch also writes each mode's visible-band pext, pabs, pasm
+                    # for the diagnostics kernel (3 x nmodes doubles per cell): an intermediate of this design, reported beside
+                    # the algorithmic bytes (handover_bytes_per_column), not counted in them
+                    "modal_aero_sw": BYTES["modal_aero_sw"](pver),
                     "modal_aero_lw": BYTES["modal_aero_lw"](pver)}
         # share of one substep: geopotential_t and physics_update run three times
         share = {k: v * (3 if k in ("geopotential_t", "physics_update") else 1) for k, v in kern_ms.items()}
@@ -336,6 +338,7 @@ def main():
                     "algorithmic_gb_per_launch": round(per_call[dom] * units / 1e9, 4),
                     "avg_launch_ms": round(kern_ms[dom], 4), "bytes_per_column": per_call[dom], "columns_per_launch": units,
                     "kernel_ms": {k: round(v, 4) for k, v in kern_ms.items()},
+                    "handover_bytes_per_column": (3 * 4 * pver * 8 if (sw_diag and dom == "modal_aero_sw") else 0),
                     "substep_bytes_per_column": substep_bytes(pver, with_aero and sw_diag),
                     "substep_hbm_frac": round(substep_bytes(pver, with_aero and sw_diag) * value / world / 1e9 / HBM_PEAK_GBS, 6),
                     "note": "path is fp64-transcendental / latency bound, not HBM bound (SURVEY.md 0-4, 8d)",
