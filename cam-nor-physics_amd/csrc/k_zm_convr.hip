@@ -1552,18 +1552,16 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
         if (atoi(e) == 2) paired = false;
     }
     // lane pairs (two lanes per column, colphys_common.h): the second ascent always (it covers the ~10 % triggered
-    // columns, the SIMDs are empty: 0.57 -> 0.49 ms); not the trigger, whose 1 520 waves already keep two dependent
-    // chains on every SIMD -- twice the waves at 0.8x the length each is 1.03 ms against 0.76 (measured, 48 602 columns).
+    // columns, the SIMDs are empty: 0.57 -> 0.49 ms); the trigger only while its twice-as-many waves still find a SIMD each
+    // (up to 16 384 columns: 0.58 -> 0.42 ms, a chunk-sized call 1.06 -> 0.96 ms, a 6 075-column share of a strong-scaled grid
+    // 1.28 -> 1.12 ms per ZM substep; at 20 000 columns it is already 0.64 against 0.58, at 48 602 1.03 against 0.76).
     // COLPHYS_LPC_TRIG / COLPHYS_LPC_ASC = 1 / 2 force the choice (experiments).
-    static int lpc_trig_env = -1, lpc_asc_env = -1;
-    if (lpc_trig_env < 0) {
-        const char *e = getenv("COLPHYS_LPC_TRIG");
-        lpc_trig_env = e ? atoi(e) : 0;
-        e = getenv("COLPHYS_LPC_ASC");
-        lpc_asc_env = e ? atoi(e) : 0;
-    }
+    int lpc_trig_env = 0, lpc_asc_env = 0;             // read per call: tests switch them between calls
+    if (const char *e = getenv("COLPHYS_LPC_TRIG")) lpc_trig_env = atoi(e);
+    if (const char *e = getenv("COLPHYS_LPC_ASC")) lpc_asc_env = atoi(e);
     const int nblk32 = (ncol + 31) / 32;
-    int lpc_trig = 1;
+    // ... unless its lane pairs still leave SIMDs idle: a chunk-sized call, or a rank's share of a strong-scaled grid
+    int lpc_trig = (2 * nblk32 <= n_simd) ? 2 : 1;
     if (lpc_trig_env == 1 || lpc_trig_env == 2) lpc_trig = lpc_trig_env;
     int lpc_asc = 2;
     if (lpc_asc_env == 1 || lpc_asc_env == 2) lpc_asc = lpc_asc_env;

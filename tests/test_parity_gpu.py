@@ -61,13 +61,15 @@ def check_zm(o, ref, ncol, pcols=cases.PCOLS):
 # ---------------------------------------------------------------------------------------------------
 # (a) golden fixtures = outputs of the reference Fortran
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("trig_mode", ["auto", "fused", "plume-pairs"])
+@pytest.mark.parametrize("trig_mode", ["auto", "one-lane", "fused", "plume-pairs"])
 @pytest.mark.parametrize("name", cases.ZM_GOLDEN)
 def test_zm_convr_vs_reference_golden(name, trig_mode, monkeypatch):
     """both mappings of the first ascent: wave pairs (what these column counts select) and the single-wave kernel
     that takes over when the column groups fill the SIMDs (forced here through COLPHYS_TRIG_MODE); and the plume kernels with
     two columns per wave, which large column counts at up to 32 levels select (forced through COLPHYS_PLUME_CPW; L70 keeps
     one column per wave whatever the setting)"""
+    if trig_mode == "one-lane":                       # the wave-pair trigger with one lane per column (what > 16 384 columns select;
+        monkeypatch.setenv("COLPHYS_LPC_TRIG", "1")   # these column counts take two lanes per column by themselves)
     if trig_mode == "fused":
         monkeypatch.setenv("COLPHYS_TRIG_MODE", "2")
     if trig_mode == "plume-pairs":
