@@ -1002,6 +1002,41 @@ def test_argument_errors_are_refused_before_any_launch():
     del d, o
 
 
+def test_finalize_and_reinitialise():
+    """colphys_finalize releases everything the library holds: compute calls are refused until colphys_init, the optics until
+    their tables are set again, and the second life gives the numbers of the first (three cycles: nothing accumulates)."""
+    import ctypes as C
+    from cam_nor_physics_amd.engine import ColphysError
+    pver, ncol = 32, 200
+    params = cases.default_params(pver)
+    eng = engine(params)
+    props = synth.make_aero_props(3)
+    st = synth.make_state(ncol, pver, 3)
+    aer = synth.make_aero_state(ncol, pver, props, 3)
+    args = cases.zm_args_from_state(st, st["zi"], st["zm"])
+
+    def life():
+        eng.aero_tables_set(props, synth.PHYSCONST)
+        d = eng.dev
+        z = run_zm(eng, args)
+        lw = to_np(eng.modal_aero_lw(d(st["pdeldry"]), d(aer["specmmr"]), d(aer["dgnumwet"]), d(aer["qaerwat"])))
+        return z, lw
+    z0, lw0 = life()
+    for _ in range(3):
+        assert eng.lib.colphys_finalize() == 0 and eng.lib.colphys_is_initialized() == 0
+        with pytest.raises(ColphysError, match="colphys_init"):
+            run_zm(eng, args)
+        assert eng.lib.colphys_finalize() == 0                     # twice is harmless
+        assert eng.lib.colphys_init(0, C.byref(params)) == 0 and eng.lib.colphys_is_initialized() == 1
+        d = eng.dev
+        with pytest.raises(ColphysError, match="colphys_aero_tables_set"):
+            eng.modal_aero_lw(d(st["pdeldry"]), d(aer["specmmr"]), d(aer["dgnumwet"]), d(aer["qaerwat"]))
+        z, lw = life()
+        for k in z0:
+            assert np.array_equal(z[k], z0[k]), k
+        assert np.array_equal(lw["tauxar"], lw0["tauxar"])
+
+
 def test_no_column_convects():
     """dry soundings: every chunk takes the reference's early return (lengath = 0, zm_conv.F90:917), outputs are the
     initial zeros / defaults, and the second-ascent / plume launches find an empty list"""
