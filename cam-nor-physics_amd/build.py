@@ -42,6 +42,9 @@ def build_hip(force: bool = False, verbose: bool = False, extra_flags=(), out: s
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    if out is not None:                 # an experiment build: its objects are of no further use (and would travel with gpurun)
+        for o in objs:
+            os.remove(o)
     return lib
 
 
