@@ -114,6 +114,7 @@ module colphys_resident
   public :: colphys_modal_aero_sw_dev, colphys_modal_aero_lw_dev, colphys_modal_aero_sw_diag_dev
   public :: colphys_alloc, colphys_alloc_int, colphys_release, colphys_upload, colphys_upload_multi, colphys_upload_int, &
             colphys_download, colphys_download_int, colphys_download_gathered_sets, colphys_sync
+  public :: colphys_check_zm_status, colphys_check_optics_status
 
 contains
 
@@ -123,6 +124,63 @@ contains
     character(len=*), intent(in) :: what
     if (rc /= 0) call endrun('colphys_resident: '//what//' failed')
   end subroutine check
+
+  ! ---- what the reference ends the run on, for a whole rank (the per-chunk shim does the same per call) ---------------------
+  ! status(pcols, nchunks): the downloaded status words of colphys_zm_conv_tend_dev / colphys_zm_convr_dev
+  subroutine colphys_check_zm_status(status, ncol)
+    use cam_abortutils, only: endrun
+    use cam_logfile,    only: iulog
+    integer(c_int32_t), intent(in) :: status(:, :)
+    integer, intent(in) :: ncol(:)
+    integer :: c, i
+    do c = 1, size(status, 2)
+      do i = 1, ncol(c)
+        if (iand(status(i, c), COLPHYS_STATUS_BRENT_NOT_CONVERGED) /= 0) then
+          if (iand(status(i, c), COLPHYS_STATUS_BRENT_ENTHALPY) /= 0) then     ! the inversions a column meets first (zm_conv.F90:5102)
+            write(iulog,*) '*** ZM_CONV: IENTHALPY: Failed and about to exit, chunk,icol= ', c, i
+            call endrun('**** ZM_CONV IENTHALPY: Tmix did not converge ****')                 ! zm_conv.F90:5565
+          end if
+          write(iulog,*) '*** ZM_CONV: IENTROPY: Failed and about to exit, chunk,icol= ', c, i
+          call endrun('**** ZM_CONV IENTROPY: Tmix did not converge ****')                    ! zm_conv.F90:5409
+        end if
+      end do
+    end do
+  end subroutine colphys_check_zm_status
+
+  ! status words of colphys_modal_aero_sw_dev / _lw_dev.  nerr_dopaer: the caller's running count (the reference keeps one in
+  ! modal_aero_sw and one in modal_aero_lw, SAVEd); nerrmax < 0: the count alone never halts (modal_aero_sw), 1000 in
+  ! modal_aero_lw (modal_aer_opt.F90:619-620, 1024-1026, 1275-1276, 1432-1434)
+  subroutine colphys_check_optics_status(subname, status, ncol, nerr_dopaer, nerrmax)
+    use cam_abortutils, only: endrun
+    use cam_logfile,    only: iulog
+    character(len=*), intent(in) :: subname
+    integer(c_int32_t), intent(in) :: status(:, :)
+    integer, intent(in) :: ncol(:), nerrmax
+    integer, intent(inout) :: nerr_dopaer
+    integer :: c, i
+    logical :: negative
+    character(len=12) :: num
+    negative = .false.
+    do c = 1, size(status, 2)
+      do i = 1, ncol(c)
+        if (iand(status(i, c), COLPHYS_STATUS_DOPAER_RANGE) /= 0) then
+          if (iand(status(i, c), COLPHYS_STATUS_DOPAER_NEGATIVE) /= 0) then
+            write(iulog,*) 'ERROR: Negative aerosol optical depth in this layer.'
+            negative = .true.
+          else
+            write(iulog,*) 'WARNING: Aerosol optical depth is unreasonably high in this layer.'
+          end if
+          write(iulog,*) subname//': chunk=', c, ' column=', i, ' layers out of range=', ishft(status(i, c), -COLPHYS_STATUS_COUNT_SHIFT)
+          nerr_dopaer = nerr_dopaer + ishft(status(i, c), -COLPHYS_STATUS_COUNT_SHIFT)
+        end if
+      end do
+    end do
+    if (negative .or. (nerrmax >= 0 .and. nerr_dopaer >= nerrmax)) then
+      write(num, '(i0)') nerr_dopaer
+      write(iulog,*) '*** halting in ', subname, ' after nerr_dopaer =', nerr_dopaer
+      call endrun('*** halting in '//subname//' after nerr_dopaer = '//trim(num))
+    end if
+  end subroutine colphys_check_optics_status
 
   subroutine colphys_alloc(f, nrows, nlev)          ! fp64 field
     type(colphys_field), intent(inout) :: f

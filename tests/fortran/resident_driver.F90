@@ -87,6 +87,7 @@ subroutine res_zm_conv_tend(nchunks, ncol, ztodt, dycore_kind, qmin,            
   st = 0
   call colphys_download_int(f_status, st, pcols, nchunks, ncol)
   nbad = count(st /= 0)
+  call colphys_check_zm_status(st, ncol)            ! ends the run where the reference's ientropy / ienthalpy would
 
   do i = 1, NIN;   call colphys_release(f_in(i));  end do
   do i = 1, NMID;  call colphys_release(f_mid(i)); end do
@@ -120,6 +121,7 @@ subroutine res_modal_aero(nchunks, ncol, nmodes, nspec_max, nsw, nlw, pdeldry, p
   type(colphys_field) :: f_pd, f_pm, f_t, f_mmr, f_dg, f_qw, f_tl, f_out(5), f_vis, f_lev, f_col, f_st
   type(colphys_modal_aero_io) :: io
   integer :: nrows, i, rc, st(pcols, nchunks), f
+  integer, save :: nerr_dopaer_sw = 0
   type(colphys_field) :: view
 
   nrows = nchunks * pcols
@@ -144,6 +146,7 @@ subroutine res_modal_aero(nchunks, ncol, nmodes, nspec_max, nsw, nlw, pdeldry, p
   st = 0
   call colphys_download_int(f_st, st, pcols, nchunks, ncol)
   nbad = count(st /= 0)
+  call colphys_check_optics_status('modal_aero_sw', st, ncol, nerr_dopaer_sw, -1)   ! warns / counts / halts as modal_aero_sw does
   call colphys_download(f_out(1), tauxar, pcols, pverp*nsw, nchunks, ncol); call colphys_download(f_out(2), wa, pcols, pverp*nsw, nchunks, ncol)
   call colphys_download(f_out(3), ga, pcols, pverp*nsw, nchunks, ncol);     call colphys_download(f_out(4), fa, pcols, pverp*nsw, nchunks, ncol)
   ! the packed diagnostics are field-major on the device: one view per field

@@ -38,20 +38,8 @@ def from_cam(a, ncol):
     return out
 
 
-@pytest.mark.parametrize("ncol", [16 * 40, 16 * 40 - 6])
-def test_fortran_whole_node_zm_conv_tend_matches_python_engine(ncol):
-    from test_parity_gpu import engine
-    pver = 32
-    lib = C.CDLL(os.path.join(ROOT, "cam-nor-physics_amd", "_build", f"libcolphys_shim_p{PCOLS}_l{pver}.so"))
-    params = cases.default_params(pver)
-    eng = engine(params)                                    # colphys_init: the Fortran caller shares the engine instance
-    st = synth.make_state(ncol, pver, 515)
-    d = eng.dev
-    S = {k: d(st[k]) for k in ("t", "q", "u", "v", "pint", "pmid", "pdel", "rpdel", "lnpint", "lnpmid", "pdeldry", "phis",
-                               "pblh", "tpert", "landfrac", "cld", "rair", "zvir", "zi", "zm")}
-    S["ps"] = d(st["pint"][:, -1].copy())
-    want = {k: v.cpu().numpy() for k, v in eng.zm_conv_tend(S, synth.ZTODT, pcols=PCOLS).items()}
-
+def call_res_zm_conv_tend(lib, st, ncol, pver):
+    """tests/fortran/resident_driver.F90 res_zm_conv_tend on CAM-layout copies of a dense state"""
     nchunks = (ncol + PCOLS - 1) // PCOLS
     ncols = np.array([min(PCOLS, ncol - c * PCOLS) for c in range(nchunks)], dtype=np.int32)
     names_in = ("t", "q", "u", "v", "pmid", "pint", "pdel", "rpdel", "lnpint", "lnpmid", "zm", "zi", "phis", "ps", "rair", "zvir",
@@ -70,7 +58,62 @@ def test_fortran_whole_node_zm_conv_tend_matches_python_engine(ncol):
     lib.res_zm_conv_tend(C.c_int(nchunks), ip(ncols), C.c_double(synth.ZTODT), C.c_int(abi.DYCORE_FV), C.c_double(1.0e-12),
                          *[dp(a) for a in ins], *[dp(outs[k]) for k in names_out], ip(jt), ip(maxg), ip(ideep), ip(lengath),
                          C.byref(nbad))
-    assert nbad.value == 0
+    return outs, jt, maxg, ideep, lengath, nbad.value
+
+
+_HALT = r"""
+import ctypes as C, os, sys
+import numpy as np
+root = sys.argv[1]
+for p in (root, os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+import cases
+import test_fortran_resident_gpu as T
+from cam_nor_physics_amd import synth
+from cam_nor_physics_amd.engine import ColumnPhysics
+pver, ncol = 32, 16 * 6 - 3
+eng = ColumnPhysics(cases.default_params(pver), 0)          # first: the process's HIP runtime is the one torch brings
+lib = C.CDLL(os.path.join(root, "cam-nor-physics_amd", "_build", "libcolphys_shim_p16_l32.so"))
+st = synth.make_state(ncol, pver, 5)
+if sys.argv[2] == "nan":
+    st["t"] = st["t"].copy(); st["t"][37, :] = np.nan
+print("NBAD", T.call_res_zm_conv_tend(lib, st, ncol, pver)[-1])
+"""
+
+
+@pytest.mark.parametrize("case,halts", [("clean", False), ("nan", True)])
+def test_fortran_whole_node_status_check_halts_like_the_reference(case, halts):
+    """colphys_check_zm_status (colphys_resident.F90) on the status words of the whole rank: a sounding that is not a number
+    ends the run with the reference's ienthalpy message (zm_conv.F90:5565; endrun here is the stand-in that stops the
+    process, hence the child process); clean soundings return."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _HALT, ROOT, case], capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    if halts:
+        assert r.returncode != 0 and "NBAD" not in r.stdout, out[-2000:]
+        assert "ENDRUN:" in out and "**** ZM_CONV IENTHALPY: Tmix did not converge ****" in out, out[-2000:]
+    else:
+        assert r.returncode == 0 and "NBAD 0" in r.stdout and "ENDRUN:" not in out, out[-2000:]
+
+
+@pytest.mark.parametrize("ncol", [16 * 40, 16 * 40 - 6])
+def test_fortran_whole_node_zm_conv_tend_matches_python_engine(ncol):
+    from test_parity_gpu import engine
+    pver = 32
+    lib = C.CDLL(os.path.join(ROOT, "cam-nor-physics_amd", "_build", f"libcolphys_shim_p{PCOLS}_l{pver}.so"))
+    params = cases.default_params(pver)
+    eng = engine(params)                                    # colphys_init: the Fortran caller shares the engine instance
+    st = synth.make_state(ncol, pver, 515)
+    d = eng.dev
+    S = {k: d(st[k]) for k in ("t", "q", "u", "v", "pint", "pmid", "pdel", "rpdel", "lnpint", "lnpmid", "pdeldry", "phis",
+                               "pblh", "tpert", "landfrac", "cld", "rair", "zvir", "zi", "zm")}
+    S["ps"] = d(st["pint"][:, -1].copy())
+    want = {k: v.cpu().numpy() for k, v in eng.zm_conv_tend(S, synth.ZTODT, pcols=PCOLS).items()}
+
+    nchunks = (ncol + PCOLS - 1) // PCOLS
+    outs, jt, maxg, ideep, lengath, nbad = call_res_zm_conv_tend(lib, st, ncol, pver)
+    assert nbad == 0
     for k in ("ptend_s", "ptend_q", "ptend_u", "ptend_v", "mconzm", "evapcdp"):
         assert np.array_equal(from_cam(outs[k], ncol), want[k]), k
     for k in ("prec", "snow", "rliq", "jctop", "jcbot"):
