@@ -739,6 +739,45 @@ def test_full_size_column_independence_and_gather(monkeypatch):
         assert np.all((o["prec"] >= 0)) and np.all(o["prec"][~np.isin(np.arange(ncol), src)] == 0)
 
 
+def test_ne120_size_repeats_its_tiles():
+    """777 728 columns (BASELINE.json's ne120-sized config, rounded to whole chunks of a 48 608-column slab repeated 16 times):
+    every repetition gives the first one's results bit for bit -- per-column outputs and, the slab being whole chunks, the
+    gathered sets too -- so no index or offset breaks beyond 2^31 bytes; the optics the same way at 388 864 columns, where the
+    four SW outputs are 1.4 GB each."""
+    base, rep, pver = 48608, 16, 32
+    eng = engine(cases.default_params(pver))
+    st = synth.make_state(base, pver, 120)
+    args = cases.zm_args_from_state(st, st["zi"], st["zm"])
+    big = tuple(np.tile(a, (rep,) + (1,) * (a.ndim - 1)) if isinstance(a, np.ndarray) else a for a in args)
+    o = run_zm(eng, big)
+    assert o["lengath"].sum() > 0.03 * base * rep and not o["status"].any()
+    nch = base // 16
+    for k, v in o.items():
+        n0 = nch if k == "lengath" else base
+        first = v[:n0]
+        for r in (1, rep // 2, rep - 1):
+            assert np.array_equal(v[r * n0:(r + 1) * n0], first), (k, r)
+    del o, big
+    props = synth.make_aero_props(120)
+    aer = synth.make_aero_state(base, pver, props, 120)
+    eng.aero_tables_set(props, synth.PHYSCONST)
+    rep = 8
+    d = eng.dev
+    tile = lambda a, ax: np.concatenate([a] * rep, axis=ax)
+    a = (d(tile(st["pdeldry"], 0)), d(tile(aer["specmmr"], 2)), d(tile(aer["dgnumwet"], 1)), d(tile(aer["qaerwat"], 1)))
+    sw = eng.modal_aero_sw(*a)
+    lw = eng.modal_aero_lw(*a)
+    eng.torch.cuda.synchronize()
+    for name, v in (("tauxar", sw["tauxar"]), ("wa", sw["wa"]), ("ga", sw["ga"]), ("fa", sw["fa"]), ("lw", lw["tauxar"])):
+        first = v[:base]
+        assert bool((first > 0).any()), name
+        for r in (1, rep - 1):
+            assert bool(eng.torch.equal(v[r * base:(r + 1) * base], first)), (name, r)
+    assert not bool(sw["status"].any()) and not bool(lw["status"].any())
+    del sw, lw, a
+    eng.torch.cuda.empty_cache()
+
+
 def test_full_size_water_budgets():
     """48 602 columns x L32, the closed budgets the reference's formulation implies:
     zm_convr -- precipitation is the column-integrated drying minus the detrained liquid (zm_conv.F90:1629-1638);
