@@ -751,10 +751,12 @@ def test_ne120_size_repeats_its_tiles():
     big = tuple(np.tile(a, (rep,) + (1,) * (a.ndim - 1)) if isinstance(a, np.ndarray) else a for a in args)
     o = run_zm(eng, big)
     assert o["lengath"].sum() > 0.03 * base * rep and not o["status"].any()
+    small = run_zm(eng, args)             # the slab alone takes other kernel variants (wave-pair trigger, one column per plume wave)
     nch = base // 16
     for k, v in o.items():
         n0 = nch if k == "lengath" else base
         first = v[:n0]
+        assert np.array_equal(first, small[k]), k
         for r in (1, rep // 2, rep - 1):
             assert np.array_equal(v[r * n0:(r + 1) * n0], first), (k, r)
     del o, big
