@@ -780,12 +780,13 @@ def test_ne120_size_repeats_its_tiles():
     eng.torch.cuda.empty_cache()
 
 
-def test_full_size_water_budgets():
-    """48 602 columns x L32, the closed budgets the reference's formulation implies:
+@pytest.mark.parametrize("pver", [32, 70])
+def test_full_size_water_budgets(pver):
+    """48 602 columns x L32 and x L70 (BASELINE.json's high-top config), the closed budgets the reference's formulation implies:
     zm_convr -- precipitation is the column-integrated drying minus the detrained liquid (zm_conv.F90:1629-1638);
     zm_conv_evap -- the precipitation flux at the surface is the column sum of the net production, what evaporates is
     what moistens, and the heating is the latent heat of those two (zm_conv.F90:1943-1966)."""
-    ncol, pver = 48602, 32
+    ncol = 48602
     eng = engine(cases.default_params(pver))
     st = synth.make_state(ncol, pver, 78)
     args = cases.zm_args_from_state(st, st["zi"], st["zm"])
