@@ -37,6 +37,21 @@ __device__ __forceinline__ void tile_in(double *s, const double *g, int nc, int 
         s[c * ldk + k] = g[i];
     }
 }
+// NF tiles of the same shape in ONE pass: the NF loads of a cell are in flight together (NF separate tile_in loops are NF
+// times as many dependent global round trips: each loop's LDS stores wait for its own loads)
+template <int NF>
+__device__ __forceinline__ void tile_in_n(double *const (&s)[NF], const double *const (&g)[NF], int nc, int nlev, int ldk)
+{
+    const int n = nc * nlev;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int c = i / nlev, k = i - c * nlev;
+        double v[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) v[f] = g[f][i];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) s[f][c * ldk + k] = v[f];
+    }
+}
 __device__ __forceinline__ void tile_out(double *g, const double *s, int nc, int nlev, int ldk)
 {
     const int n = nc * nlev;
@@ -260,12 +275,12 @@ __global__ __launch_bounds__(ENT) void zm_conv_evap_kernel(ZmDev P, const double
     double *sFS = sFP + ETILE * ldp;    // flxsnow [ldp]
 
     for (int i = threadIdx.x; i <= COLPHYS_PLENEST; i += ENT) s_estbl[i] = estbl[i];
-    tile_in(sT, io.t + col0 * L, nc, pver, ld);
-    tile_in(sPM, io.pmid + col0 * L, nc, pver, ld);
-    tile_in(sPD, io.pdel + col0 * L, nc, pver, ld);
-    tile_in(sQ, io.q + col0 * L, nc, pver, ld);
-    tile_in(sPR, io.prdprec + col0 * L, nc, pver, ld);
-    tile_in(sCL, io.cldfrc + col0 * L, nc, pver, ld);
+    {
+        double *const st[6] = {sT, sPM, sPD, sQ, sPR, sCL};
+        const double *const gt[6] = {io.t + col0 * L, io.pmid + col0 * L, io.pdel + col0 * L, io.q + col0 * L, io.prdprec + col0 * L,
+                                     io.cldfrc + col0 * L};
+        tile_in_n<6>(st, gt, nc, pver, ld);
+    }
     __syncthreads();
 
     // Phase A, element-wise over the tile (all threads): everything of a level that does not depend on the fluxes coming

@@ -12,7 +12,7 @@ tag = sys.argv[1]
 try:
     d = json.load(open(f"gpurun_out/ab_{tag}.json"))
     k = d["roofline"]["kernel_ms"]
-    print(f"{tag:28s} {d['ms_per_step']:.4f} ms/step | " + " ".join(f"{n}={k[n]:.3f}" for n in ("zm_trigger", "zm_ascent2", "zm_plume2", "modal_aero_sw", "modal_aero_lw") if n in k), flush=True)
+    print(f"{tag:28s} {d['ms_per_step']:.4f} ms/step | " + " ".join(f"{n}={k[n]:.3f}" for n in ("zm_trigger", "zm_ascent2", "zm_plume2", "zm_conv_evap", "modal_aero_sw", "modal_aero_lw") if n in k), flush=True)
 except Exception as e:
     print(tag, "FAILED", open(f"gpurun_out/ab_{tag}.err").read()[-400:], flush=True)
 PY
