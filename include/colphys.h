@@ -63,7 +63,8 @@
  *     work arrays (zm_convr, zm_conv_tend, convtran / zm_conv_tend_2) must be ordered by the caller -- one stream, or events
  *     between streams -- the others (geopotential, zm_conv_evap, momtran, the optics, the updates) are free of shared state.
  *     colphys_init / colphys_aero_tables_set / colphys_finalize are not to overlap with compute calls.  Every call leaves
- *     the calling thread on the engine's HIP device; colphys_last_error() is per calling thread.
+ *     the calling thread on the engine's HIP device; colphys_last_error() is per calling thread.  The per-kernel timers
+ *     (colphys_profile_enable) are a measurement mode for one calling thread.
  */
 #ifndef COLPHYS_H
 #define COLPHYS_H
