@@ -85,7 +85,11 @@ def run_cpu_baseline(st, aer, props, pver, with_aero=True, cores=None, sample_co
     if kind == "reference" and not have_ref(16, pver):
         return None
     ncol = st["ncol"] if sample_cols is None else min(sample_cols, st["ncol"])
-    cores = cores or min(16, os.cpu_count() or 1)
+    if not cores:                       # every core this process may use (bench.py passes min(affinity, cgroup quota))
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cores = os.cpu_count() or 1
     _G.update(st=st, aer=aer, props=props, with_aero=with_aero)
     # slices aligned to the reference's chunk width
     nchunks = (ncol + 15) // 16

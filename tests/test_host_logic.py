@@ -55,3 +55,46 @@ def test_tolerance_helpers():
         assert_close("i", np.array([1, 2], dtype=np.int32), np.array([1, 3], dtype=np.int32))
     m = gathered_mask(np.array([2, 0, 1]), 40, 16)
     assert m.sum() == 3 and m[0] and m[1] and m[32] and not m[16]
+
+
+def test_bench_host_info_and_pmc_stamp_logic(tmp_path, monkeypatch):
+    """bench.py's host description and its refusal of a PMC summary taken from other kernel sources"""
+    import json
+    import bench
+    h = bench.host_info()
+    assert 1 <= h["usable_cores"] <= h["sched_affinity"] and isinstance(h["cpu_model"], str)
+    sha = bench.kernel_source_hash()
+    assert len(sha) == 16 and sha == bench.kernel_source_hash()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: sha)
+    assert bench.pmc_file()[0] is None
+    (prof / "r09_pmc_summary.csv").write_text('kernel,FETCH_SIZE,WRITE_SIZE\n"modal_aero_reg_kernel<true, true, true>",1000,500\n')
+    assert bench.pmc_file()[0] is None and "stamp" in bench.pmc_file()[1]
+    (prof / "r09_pmc_summary.json").write_text(json.dumps({"kernel_source_sha16": "0" * 16}))
+    assert bench.pmc_file()[0] is None and "stale" in bench.pmc_file()[1]
+    (prof / "r09_pmc_summary.json").write_text(json.dumps({"kernel_source_sha16": sha}))
+    path, why = bench.pmc_file()
+    assert why is None and bench.pmc_of("modal_aero_sw", path)["traffic"] == round((2 * 1000 + 500) * 1024 / 1e9, 4)
+
+
+def test_bench_parent_of_a_multi_gpu_run_spawns_before_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher hands over to torch.distributed.run as a child and returns its code"""
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, cwd=None):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    assert bench.spawn_ranks(4) == 7
+    c = seen["cmd"]
+    assert c[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in c and c[c.index("--nproc-per-node") + 1] == "4"
+    assert c[c.index("--master-addr") + 1] == "127.0.0.1" and c[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in seen["env"]
+    assert "torch" not in [m for m in ("torch",) if m in bench.__dict__]       # the parent module itself never imported torch
