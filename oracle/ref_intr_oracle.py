@@ -1,0 +1,199 @@
+"""TEST INFRASTRUCTURE -- ctypes front end of oracle/_ref/liboracle_refintr_p<pcols>_l<pver>.so.
+
+That library is the reference's own OPERATOR layer -- physics/physics_types.F90 (physics_update, physics_ptend_sum,
+set_state_pdry, set_wet_to_dry), physics/zm_conv_intr.F90 (zm_conv_tend, zm_conv_tend_2) and
+physics/convect_diagnostics.F90 (convect_diagnostics_calc) -- compiled unmodified by oracle/Makefile on top of the
+reference's zm_conv.F90 / geopotential.F90, behind the bind(C) wrappers of oracle/ref_wrap_intr.F90.  The same front end
+drives the shim twin (cam-nor-physics_amd/_build/libcolphys_shimintr_*.so): the reference's zm_conv_tend on the HIP engine.
+Only tests/ and tests/golden/make_golden.py may import this module.
+
+Arrays are numpy float64 [ncol][pver] (interfaces [ncol][pver+1]); constituents [pcnst][ncol][pver], pcnst = 40 here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import tempfile
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_D = C.POINTER(C.c_double)
+_I = C.POINTER(C.c_int)
+
+HIST_COL = ("CAPE", "EURT", "FREQZM", "PCONVT", "PCONVB", "PRECCDZM", "PRECZ")
+HIST_LEV = ("ZMMU", "ZMMD", "ZMDT", "ZMDQ", "DIFZM", "DLFZM", "EVAPTZM", "FZSNTZM", "EVSNTZM", "EVAPQZM", "ZMNTPRPD", "ZMNTSNPD",
+            "ZMEIHEAT", "ZMMTT", "ZMMTU", "ZMMTV", "ZMUPGU", "ZMUPGD", "ZMVPGU", "ZMVPGD", "ZMICUU", "ZMICUD", "ZMICVU", "ZMICVD",
+            "ZMDICE", "ZMDLIQ")
+HIST_INT = ("CMFMC_DP", "ZMFLXPRC", "ZMFLXSNW")
+
+
+def refintr_lib_path(pcols: int, pver: int) -> str:
+    return os.path.join(_HERE, "_ref", f"liboracle_refintr_p{pcols}_l{pver}.so")
+
+
+def have_refintr(pcols: int, pver: int) -> bool:
+    return os.path.exists(refintr_lib_path(pcols, pver))
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _d(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
+    return a.ctypes.data_as(_D)
+
+
+def _i(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_I)
+
+
+def write_zmconv_nl(path, nl):
+    """the &zmconv_nl group zm_conv_readnl reads (zm_conv_intr.F90:187-191) from the dictionary form of synth.ZM_NAMELIST"""
+    def lg(x):
+        return ".true." if x else ".false."
+    with open(path, "w") as f:
+        f.write("&zmconv_nl\n")
+        for k in ("c0_lnd", "c0_ocn", "ke", "ke_lnd", "momcu", "momcd", "dmpdz", "tiedke_add", "capelmt", "tau"):
+            f.write(f" zmconv_{k} = {float(nl[k])!r}\n")      # list-directed input converts to the variable's kind (r8): exact
+        f.write(f" zmconv_num_cin = {int(nl['num_cin'])}\n zmconv_org = {lg(nl['org'])}\n zmconv_microp = {lg(nl['microp'])}\n"
+                f" zmconv_parcel_pbl = {lg(nl['parcel_pbl'])}\n/\n")
+
+
+class RefIntrOracle:
+    def __init__(self, namelist: dict, pref_edge, pcols: int = 16, pver: int = 32, lib_path: str | None = None,
+                 isdry=None, lq1=None, lq2=None, qmin=None):
+        """namelist: synth.ZM_NAMELIST-shaped; pref_edge: reference interface pressures [pver+1] (zm_conv_init derives limcnv
+        from them, zm_conv_intr.F90:356-368).  isdry / lq1 / lq2 / qmin: per-constituent tables [pcnst] (cnst_type == 'dry',
+        cnst_is_convtran1, cnst_is_convtran2, the qneg3 minima); defaults: everything wet, cloud liquid and ice (2, 3) in
+        convtran1, constituents 4.. in convtran2, qmin(1) = 1e-12 and 0 beyond."""
+        self.lib = C.CDLL(lib_path or refintr_lib_path(pcols, pver))
+        v = [C.c_int() for _ in range(6)]
+        self.lib.ref_intr_dims(*[C.byref(x) for x in v])
+        assert (v[0].value, v[1].value) == (pcols, pver)
+        self.pcols, self.pver, self.pcnst = pcols, pver, v[2].value
+        assert (v[3].value, v[4].value, v[5].value) == (len(HIST_COL), len(HIST_LEV), len(HIST_INT))
+        n = self.pcnst
+        self.isdry = np.zeros(n, np.int32) if isdry is None else np.ascontiguousarray(isdry, np.int32)
+        self.lq1 = np.array([0, 1, 1] + [0] * (n - 3), np.int32) if lq1 is None else np.ascontiguousarray(lq1, np.int32)
+        self.lq2 = np.array([0, 0, 0] + [1] * (n - 3), np.int32) if lq2 is None else np.ascontiguousarray(lq2, np.int32)
+        self.qmin = np.array([1.0e-12] + [0.0] * (n - 1)) if qmin is None else _c(qmin)
+        with tempfile.NamedTemporaryFile("w", suffix=".nl", delete=False) as f:
+            path = f.name
+        try:
+            write_zmconv_nl(path, namelist)
+            pe = _c(pref_edge)
+            assert pe.shape == (pver + 1,)
+            b = path.encode()
+            self.lib.ref_intr_init(C.c_char_p(b), C.c_int(len(b)), _d(pe), C.c_int(int(namelist["no_deep_pbl"])), _i(self.isdry),
+                                   _i(self.lq1), _i(self.lq2), _d(self.qmin))
+        finally:
+            os.unlink(path)
+
+    def nchunks(self, n):
+        return (n + self.pcols - 1) // self.pcols
+
+    def _q_full(self, q, n):
+        """[pcnst][n][pver] from water vapour alone or from the first few constituents (the rest: a small positive constant)"""
+        q = _c(q)
+        if q.ndim == 2:
+            q = q[None]
+        full = np.full((self.pcnst, n, self.pver), 1.0e-9)
+        full[:q.shape[0]] = q
+        return full
+
+    # -- zm_conv_tend (zm_conv_intr.F90:390) ----------------------------------------------------------------------
+    def zm_conv_tend(self, st: dict, ztodt: float, q=None, fracis=None):
+        """st: synth.make_state-shaped dictionary.  q: [k][n][pver] constituents (default: st['q'] + filler), fracis likewise
+        (default 1).  Returns ptend_all, the operator's arguments, the pbuf fields it leaves, and what it handed to outfld."""
+        n, pver, pcnst = st["t"].shape[0], self.pver, self.pcnst
+        qf = self._q_full(st["q"] if q is None else q, n)
+        fr = np.ones((pcnst, n, pver)) if fracis is None else self._q_full(fracis, n)
+        ps = _c(st["pint"][:, -1])
+        o = {}
+        for k in ("ptend_s", "ptend_u", "ptend_v", "cme", "zdu", "ql", "rprd", "evapcdp", "dlf", "dif", "mu", "md", "du", "eu", "ed", "dp"):
+            o[k] = np.zeros((n, pver))
+        o["ptend_q"] = np.zeros((pcnst, n, pver))
+        for k in ("mcon", "pflx", "mconzm", "flxprec", "flxsnow"):
+            o[k] = np.zeros((n, pver + 1))
+        for k in ("rliq", "rice", "jctop", "jcbot", "prec", "snow", "dsubcld"):
+            o[k] = np.zeros(n)
+        npad = self.nchunks(n) * self.pcols
+        for k in ("jt", "maxg", "ideep"):
+            o[k] = np.zeros(npad, np.int32)
+        o["ptend_lq"] = np.zeros(pcnst, np.int32)
+        o["lengath"] = np.zeros(self.nchunks(n), np.int32)
+        hcol = np.zeros((len(HIST_COL), n)); hlev = np.zeros((len(HIST_LEV), n, pver)); hint = np.zeros((len(HIST_INT), n, pver + 1))
+        ins = [_c(st[k]) for k in ("t", "u", "v")] + [qf] + [_c(st[k]) for k in ("pmid", "pdel", "rpdel", "lnpmid", "zm", "pdeldry", "pint",
+                                                                                 "lnpint", "zi", "phis")] + [ps] + \
+              [_c(st[k]) for k in ("pblh", "tpert", "landfrac", "cld")] + [fr]
+        self.lib.ref_zm_conv_tend(
+            C.c_int(n), C.c_double(ztodt), *[_d(a) for a in ins],
+            _d(o["ptend_s"]), _d(o["ptend_u"]), _d(o["ptend_v"]), _d(o["ptend_q"]), _i(o["ptend_lq"]), _d(o["mcon"]), _d(o["pflx"]),
+            _d(o["cme"]), _d(o["zdu"]), _d(o["rliq"]), _d(o["rice"]), _d(o["jctop"]), _d(o["jcbot"]), _d(o["prec"]), _d(o["snow"]),
+            _d(o["ql"]), _d(o["rprd"]), _d(o["evapcdp"]), _d(o["dlf"]), _d(o["dif"]), _d(o["mconzm"]), _d(o["flxprec"]), _d(o["flxsnow"]),
+            _d(o["mu"]), _d(o["md"]), _d(o["du"]), _d(o["eu"]), _d(o["ed"]), _d(o["dp"]), _d(o["dsubcld"]), _i(o["jt"]), _i(o["maxg"]),
+            _i(o["ideep"]), _i(o["lengath"]), _d(hcol), _d(hlev), _d(hint))
+        for k in ("jt", "maxg", "ideep"):
+            o[k] = o[k][:n]
+        o["hist"] = {**{k: hcol[j] for j, k in enumerate(HIST_COL)}, **{k: hlev[j] for j, k in enumerate(HIST_LEV)},
+                     **{k: hint[j] for j, k in enumerate(HIST_INT)}}
+        o["q_in"], o["fracis_in"] = qf, fr
+        return o
+
+    # -- zm_conv_tend_2 (zm_conv_intr.F90:955) ----------------------------------------------------------------------
+    def zm_conv_tend_2(self, q, pdeldry, fracis, mu, md, du, eu, ed, dp, dsubcld, jt, maxg, ideep, ztodt):
+        n, pver, pcnst = pdeldry.shape[0], self.pver, self.pcnst
+        qf, fr = self._q_full(q, n), self._q_full(fracis, n)
+        npad = self.nchunks(n) * self.pcols
+
+        def ipad(a):
+            b = np.zeros(npad, np.int32)
+            b[:n] = a
+            return b
+        ptend_q = np.zeros((pcnst, n, pver)); lq = np.zeros(pcnst, np.int32)
+        self.lib.ref_zm_conv_tend_2(C.c_int(n), C.c_double(ztodt), _d(qf), _d(_c(pdeldry)), _d(fr), *[_d(_c(a)) for a in (mu, md, du, eu, ed, dp, dsubcld)],
+                                    _i(ipad(jt)), _i(ipad(maxg)), _i(ipad(ideep)), _d(ptend_q), _i(lq))
+        return ptend_q, lq
+
+    # -- convect_diagnostics_calc (convect_diagnostics.F90:115) -----------------------------------------------------
+    def convect_diagnostics(self, f: dict, ztodt: float = 1800.0):
+        """f: as tests/cases.convect_diag_case (cnt2 / cnb2 / qc2 / rliq2 inputs are ignored: the reference supports only the
+        CLUBB_SGS shallow scheme and zeroes the shallow fields, :76-78, :178-189).  Returns the updated dictionary."""
+        n, pver = f["qc"].shape
+        o = {k: _c(v).copy() for k, v in f.items()}
+        o["qc2"] = np.zeros((n, pver)); o["rliq2"] = np.zeros(n)
+        o["rprdtot"] = np.zeros((n, pver)); o["pcnt"] = np.zeros(n); o["pcnb"] = np.zeros(n)
+        self.lib.ref_convect_diagnostics_calc(
+            C.c_int(n), C.c_double(ztodt), _d(o["cmfmc"]), _d(o["qc"]), _d(o["rliq"]), _d(o["pmid"]), _d(o["cnt"]), _d(o["cnb"]),
+            _d(o["rprddp"]), _d(o["cmfmc2"]), _d(o["rprdsh"]), _d(o["icwmr"]), _d(o["evapcsh"]), _d(o["precc"]), _d(o["snow"]),
+            _d(o["qc2"]), _d(o["rliq2"]), _d(o["rprdtot"]), _d(o["pcnt"]), _d(o["pcnb"]))
+        return o
+
+    # -- physics_update (physics_types.F90:210) ---------------------------------------------------------------------
+    def physics_update(self, st: dict, dt: float, s=None, q=None, u=None, v=None):
+        """applies the given tendencies (None = that flag off) to st's t, q (water vapour), u, v; returns the updated
+        fields and the zi, zm, s physics_update derives (geopotential_t :436, dry static energy :444-447)"""
+        n, pver = st["t"].shape
+        flags = (1 if s is not None else 0) | (2 if q is not None else 0) | (4 if u is not None else 0) | (8 if v is not None else 0)
+        z = np.zeros((n, pver))
+        o = {k: _c(st[k]).copy() for k in ("t", "u", "v", "q")}
+        o["zi"] = np.full((n, pver + 1), np.nan); o["zm"] = np.full((n, pver), np.nan); o["s"] = np.full((n, pver), np.nan)
+        self.lib.ref_physics_update(
+            C.c_int(n), C.c_double(dt), C.c_int(flags), _d(o["t"]), _d(o["u"]), _d(o["v"]), _d(o["q"]),
+            *[_d(_c(st[k])) for k in ("pmid", "pdel", "rpdel", "lnpmid", "pint", "lnpint", "phis")],
+            *[_d(_c(x if x is not None else z)) for x in (s, q, u, v)], _d(o["zi"]), _d(o["zm"]), _d(o["s"]))
+        return o
+
+    # -- set_state_pdry + set_wet_to_dry + qneg3, the tail of d_p_coupling's derived fields (fv/dp_coupling.F90:630-657) ----
+    def dp_coupling_dry_tail(self, pint, pdel, q):
+        n, pver = pdel.shape
+        qf = self._q_full(q, n).copy()
+        o = {k: np.zeros((n, pver)) for k in ("pdeldry", "rpdeldry", "pmiddry", "lnpmiddry")}
+        o.update(pintdry=np.zeros((n, pver + 1)), lnpintdry=np.zeros((n, pver + 1)), psdry=np.zeros(n))
+        self.lib.ref_dp_coupling_dry_tail(C.c_int(n), _d(_c(pint)), _d(_c(pdel)), _d(qf), _d(o["pdeldry"]), _d(o["rpdeldry"]),
+                                          _d(o["pmiddry"]), _d(o["lnpmiddry"]), _d(o["pintdry"]), _d(o["lnpintdry"]), _d(o["psdry"]))
+        o["q"] = qf
+        return o

@@ -1,0 +1,496 @@
+! TEST INFRASTRUCTURE -- not product code.
+!
+! bind(C) entry points around the reference's OPERATOR layer, compiled UNMODIFIED and in place from /root/reference by
+! oracle/Makefile (target ref_intr):
+!     physics/physics_types.F90        physics_state / physics_ptend, physics_update :210, physics_ptend_sum :698,
+!                                      physics_state_copy :1797, set_state_pdry :1925, set_wet_to_dry :1968
+!     physics/zm_conv_intr.F90         zm_conv_register :101, zm_conv_readnl :176, zm_conv_init :244, zm_conv_tend :390,
+!                                      zm_conv_tend_2 :955
+!     physics/convect_diagnostics.F90  convect_diagnostics_register :50, _init :91, convect_diagnostics_calc :115
+! on top of zm_conv.F90 / geopotential.F90 -- the reference's own (oracle library) or, in the shim twin
+! (cam-nor-physics_amd/fortran/Makefile, target intr), the ISO_C_BINDING shim's modules of the same names: there the
+! reference's zm_conv_tend runs on the HIP engine with not a line of it changed.
+!
+! The wrappers do what tphysbc does per chunk (physpkg.F90:1147-1161, :2820-2838): allocate a physics_state with
+! physics_state_alloc (padding columns hold +inf, physics_types.F90:2143-2178), fill columns 1:ncol, hand the chunk's
+! physics buffer over, call the operator, copy results back.  Interchange layout as in ref_wrap_zm.F90: profile arrays
+! a(pver,n) = C [n][pver]; constituents q(pver,n,pcnst) = C [pcnst][n][pver]; gathered outputs keep the per-chunk compaction.
+!
+! History output: what the operator hands to outfld is captured by name in the cam_history stand-in and returned in the
+! fixed field orders HIST_COL / HIST_LEV / HIST_INT below (tests/ and tests/golden/make_golden.py mirror them).
+
+module ref_wrap_intr
+  use iso_c_binding
+  use shr_kind_mod,        only: r8 => shr_kind_r8
+  use ppgrid,              only: pcols, pver, pverp, begchunk, endchunk
+  use physconst,           only: cpair, rair
+  use constituents,        only: pcnst, qmin, cnst_name, cnst_type, cnst_is_convtran1, cnst_is_convtran2, cnst_is_dry
+  use physics_types,       only: physics_state, physics_ptend, physics_state_alloc, physics_state_dealloc, physics_ptend_init, &
+                                 physics_ptend_dealloc, physics_update, set_state_pdry, set_wet_to_dry
+  use physics_buffer,      only: physics_buffer_desc, pbuf_add_field, pbuf_get_index, pbuf_get_field, dtype_r8, &
+                                 pbuf_allocate_2d, dyn_time_lvls, pbuf_old_tim_idx
+  use zm_conv_intr,        only: zm_conv_register, zm_conv_readnl, zm_conv_init, zm_conv_tend, zm_conv_tend_2
+  use convect_diagnostics, only: convect_diagnostics_register, convect_diagnostics_init, convect_diagnostics_calc
+  use cam_history,         only: cap_on, cap_n, outfld_captured
+  use air_composition,     only: cpairv, rairv
+  use phys_grid,           only: ncols_of_chunk
+  use phys_control,        only: deepconv_pbl_off
+  use qneg_module,         only: qneg3
+  implicit none
+  real(r8), parameter :: pad = huge(1._r8)
+  logical, save :: initialised = .false.
+  type(physics_buffer_desc), pointer, save :: pbuf2d(:,:) => null()
+  integer, save :: cld_idx = 0, fracis_idx = 0
+
+  integer, parameter :: n_hist_col = 7, n_hist_lev = 26, n_hist_int = 3
+  character(len=8), parameter :: hist_col(n_hist_col) = (/ 'CAPE    ', 'EURT    ', 'FREQZM  ', 'PCONVT  ', 'PCONVB  ', 'PRECCDZM', 'PRECZ   ' /)
+  character(len=8), parameter :: hist_lev(n_hist_lev) = (/ &
+       'ZMMU    ', 'ZMMD    ', 'ZMDT    ', 'ZMDQ    ', 'DIFZM   ', 'DLFZM   ', 'EVAPTZM ', 'FZSNTZM ', 'EVSNTZM ', 'EVAPQZM ', &
+       'ZMNTPRPD', 'ZMNTSNPD', 'ZMEIHEAT', 'ZMMTT   ', 'ZMMTU   ', 'ZMMTV   ', 'ZMUPGU  ', 'ZMUPGD  ', 'ZMVPGU  ', 'ZMVPGD  ', &
+       'ZMICUU  ', 'ZMICUD  ', 'ZMICVU  ', 'ZMICVD  ', 'ZMDICE  ', 'ZMDLIQ  ' /)
+  character(len=8), parameter :: hist_int(n_hist_int) = (/ 'CMFMC_DP', 'ZMFLXPRC', 'ZMFLXSNW' /)
+contains
+
+  subroutine ref_intr_dims(pc, pv, nc, nhc, nhl, nhi) bind(C, name='ref_intr_dims')
+    integer(c_int), intent(out) :: pc, pv, nc, nhc, nhl, nhi
+    pc = pcols; pv = pver; nc = pcnst; nhc = n_hist_col; nhl = n_hist_lev; nhi = n_hist_int
+  end subroutine ref_intr_dims
+
+  ! One-time set-up of the operator layer, in CAM's order: constituents registered, namelist read, pbuf fields
+  ! registered, pbuf allocated, init routines.  nlfile: a file holding the &zmconv_nl group (written by the caller).
+  ! isdry / lq1 / lq2: cnst_type == 'dry', cnst_is_convtran1, cnst_is_convtran2 per constituent (1 = water vapour).
+  ! zm_conv_init allocates module state of zm_conv_intr once per process: a second call only resets the data the
+  ! stand-in modules hold (constituent tables, no_deep_pbl); ZM parameters are changed through ref_zm_convi.
+  subroutine ref_intr_init(nlfile, nlen, pref_edge, no_deep_pbl, isdry, lq1, lq2, qmin_in) bind(C, name='ref_intr_init')
+    character(kind=c_char), intent(in) :: nlfile(*)
+    integer(c_int), value :: nlen, no_deep_pbl
+    real(c_double), intent(in) :: pref_edge(pverp), qmin_in(pcnst)
+    integer(c_int), intent(in) :: isdry(pcnst), lq1(pcnst), lq2(pcnst)
+    character(len=512) :: path
+    integer :: i, m
+    path = ' '
+    do i = 1, min(nlen, 512)
+      path(i:i) = nlfile(i)
+    end do
+    cnst_name(:) = ' '
+    cnst_name(1) = 'Q'; cnst_name(2) = 'CLDLIQ'; cnst_name(3) = 'CLDICE'
+    do m = 4, pcnst
+      write(cnst_name(m), '(a,i2.2)') 'TR', m
+    end do
+    do m = 1, pcnst
+      cnst_is_dry(m) = isdry(m) /= 0
+      cnst_type(m) = merge('dry', 'wet', isdry(m) /= 0)
+      cnst_is_convtran1(m) = lq1(m) /= 0
+      cnst_is_convtran2(m) = lq2(m) /= 0
+      qmin(m) = qmin_in(m)
+    end do
+    deepconv_pbl_off = no_deep_pbl /= 0
+    if (initialised) return
+    begchunk = 1; endchunk = 1
+    allocate(cpairv(pcols, pver, 1), rairv(pcols, pver, 1))
+    cpairv = cpair; rairv = rair
+    call zm_conv_readnl(trim(path))
+    call zm_conv_register()
+    ! registered elsewhere in CAM (cloud fraction package, wet deposition): the two pbuf fields zm_conv_tend looks up by name
+    call pbuf_add_field('CLD', 'global', dtype_r8, (/pcols, pver, dyn_time_lvls/), cld_idx)
+    call pbuf_add_field('FRACIS', 'physpkg', dtype_r8, (/pcols, pver, pcnst/), fracis_idx)
+    call convect_diagnostics_register()
+    call pbuf_allocate_2d(pbuf2d, 1)
+    call zm_conv_init(pref_edge)
+    call convect_diagnostics_init(pbuf2d)
+    initialised = .true.
+  end subroutine ref_intr_init
+
+  ! ---- helpers ---------------------------------------------------------------------------------------------
+  subroutine put2(src, c0, nc, nlev, dst)
+    integer, intent(in) :: c0, nc, nlev
+    real(r8), intent(in) :: src(nlev, *)
+    real(r8), intent(inout) :: dst(:,:)
+    integer :: i, k
+    do i = 1, nc
+      do k = 1, nlev
+        dst(i,k) = src(k, c0+i)
+      end do
+    end do
+  end subroutine put2
+  subroutine get2(src, c0, nc, nlev, dst)
+    integer, intent(in) :: c0, nc, nlev
+    real(r8), intent(in) :: src(:,:)
+    real(r8), intent(inout) :: dst(nlev, *)
+    integer :: i, k
+    do i = 1, nc
+      do k = 1, nlev
+        dst(k, c0+i) = src(i,k)
+      end do
+    end do
+  end subroutine get2
+  subroutine pbuf_zero(pbuf)
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    integer :: j
+    do j = 1, size(pbuf)
+      if (associated(pbuf(j)%r)) pbuf(j)%r = 0._r8
+      if (associated(pbuf(j)%i)) pbuf(j)%i = 0
+    end do
+  end subroutine pbuf_zero
+  subroutine pbuf_put2(pbuf, name, src, c0, nc, nlev)
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: c0, nc, nlev
+    real(r8), intent(in) :: src(nlev, *)
+    real(r8), pointer :: f(:,:)
+    call pbuf_get_field(pbuf, pbuf_get_index(name), f)
+    call put2(src, c0, nc, nlev, f)
+  end subroutine pbuf_put2
+  subroutine pbuf_get2(pbuf, name, dst, c0, nc, nlev)
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: c0, nc, nlev
+    real(r8), intent(inout) :: dst(nlev, *)
+    real(r8), pointer :: f(:,:)
+    call pbuf_get_field(pbuf, pbuf_get_index(name), f)
+    call get2(f, c0, nc, nlev, dst)
+  end subroutine pbuf_get2
+  subroutine pbuf_put1(pbuf, name, src, c0, nc)
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: c0, nc
+    real(r8), intent(in) :: src(*)
+    real(r8), pointer :: f(:)
+    call pbuf_get_field(pbuf, pbuf_get_index(name), f)
+    f(1:nc) = src(c0+1:c0+nc)
+  end subroutine pbuf_put1
+  subroutine pbuf_get1(pbuf, name, dst, c0, nc)
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: c0, nc
+    real(r8), intent(inout) :: dst(*)
+    real(r8), pointer :: f(:)
+    call pbuf_get_field(pbuf, pbuf_get_index(name), f)
+    dst(c0+1:c0+nc) = f(1:nc)
+  end subroutine pbuf_get1
+  subroutine pbuf_puti(pbuf, name, src, c0)
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: c0
+    integer(c_int), intent(in) :: src(*)
+    integer, pointer :: f(:)
+    call pbuf_get_field(pbuf, pbuf_get_index(name), f)
+    f(1:pcols) = src(c0+1:c0+pcols)
+  end subroutine pbuf_puti
+  subroutine pbuf_geti(pbuf, name, dst, c0, ng)
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: c0, ng
+    integer(c_int), intent(inout) :: dst(*)
+    integer, pointer :: f(:)
+    call pbuf_get_field(pbuf, pbuf_get_index(name), f)
+    dst(c0+1:c0+ng) = f(1:ng)
+  end subroutine pbuf_geti
+
+  ! a chunk's physics_state as physics_state_alloc leaves it (+inf everywhere), columns 1:nc filled
+  subroutine state_fill(state, c0, nc, t, u, v, pmid, pdel, rpdel, lnpmid, zm, pdeldry, pint, lnpint, zi, phis, ps)
+    type(physics_state), intent(inout) :: state
+    integer, intent(in) :: c0, nc
+    real(r8), intent(in) :: t(pver,*), u(pver,*), v(pver,*), pmid(pver,*), pdel(pver,*), rpdel(pver,*), lnpmid(pver,*), &
+                            zm(pver,*), pdeldry(pver,*), pint(pverp,*), lnpint(pverp,*), zi(pverp,*), phis(*), ps(*)
+    ncols_of_chunk = nc
+    call physics_state_alloc(state, 1, pcols)
+    state%ncol = nc
+    state%count = 0
+    state%ulatcnt = 0; state%uloncnt = 0
+    state%lat(:nc) = 0._r8; state%lon(:nc) = 0._r8
+    call put2(t, c0, nc, pver, state%t);        call put2(u, c0, nc, pver, state%u);       call put2(v, c0, nc, pver, state%v)
+    call put2(pmid, c0, nc, pver, state%pmid);  call put2(pdel, c0, nc, pver, state%pdel); call put2(rpdel, c0, nc, pver, state%rpdel)
+    call put2(lnpmid, c0, nc, pver, state%lnpmid); call put2(zm, c0, nc, pver, state%zm)
+    call put2(pdeldry, c0, nc, pver, state%pdeldry)
+    call put2(pint, c0, nc, pverp, state%pint); call put2(lnpint, c0, nc, pverp, state%lnpint); call put2(zi, c0, nc, pverp, state%zi)
+    state%phis(:nc) = phis(c0+1:c0+nc)
+    state%ps(:nc) = ps(c0+1:c0+nc)
+  end subroutine state_fill
+
+  ! ---- zm_conv_tend (zm_conv_intr.F90:390-905) --------------------------------------------------------------
+  subroutine ref_zm_conv_tend(n, ztodt, t, u, v, q, pmid, pdel, rpdel, lnpmid, zm, pdeldry, pint, lnpint, zi, phis, ps, &
+       pblh, tpert, landfrac, cld, fracis, &
+       ptend_s, ptend_u, ptend_v, ptend_q, ptend_lq, mcon, pflx, cme, zdu, rliq, rice, jctop, jcbot, &
+       prec, snow, ql, rprd, evapcdp, dlf, dif, mconzm, flxprec, flxsnow, mu, md, du, eu, ed, dp, dsubcld, jt, maxg, ideep, &
+       lengath, hcol, hlev, hint) bind(C, name='ref_zm_conv_tend')
+    integer(c_int), value :: n
+    real(c_double), value :: ztodt
+    real(c_double), intent(in) :: t(pver,n), u(pver,n), v(pver,n), q(pver,n,pcnst), pmid(pver,n), pdel(pver,n), rpdel(pver,n), &
+                                  lnpmid(pver,n), zm(pver,n), pdeldry(pver,n), pint(pverp,n), lnpint(pverp,n), zi(pverp,n), &
+                                  phis(n), ps(n), pblh(n), tpert(n), landfrac(n), cld(pver,n), fracis(pver,n,pcnst)
+    real(c_double), intent(inout) :: ptend_s(pver,n), ptend_u(pver,n), ptend_v(pver,n), ptend_q(pver,n,pcnst), mcon(pverp,n), &
+                                     pflx(pverp,n), cme(pver,n), zdu(pver,n), rliq(n), rice(n), jctop(n), jcbot(n), prec(n), snow(n), &
+                                     ql(pver,n), rprd(pver,n), evapcdp(pver,n), dlf(pver,n), dif(pver,n), mconzm(pverp,n), &
+                                     flxprec(pverp,n), flxsnow(pverp,n), mu(pver,n), md(pver,n), du(pver,n), eu(pver,n), ed(pver,n), &
+                                     dp(pver,n), dsubcld(n), hcol(n, n_hist_col), hlev(pver, n, n_hist_lev), hint(pverp, n, n_hist_int)
+    integer(c_int), intent(inout) :: ptend_lq(pcnst), jt(n), maxg(n), ideep(n), lengath(*)
+    type(physics_state) :: state
+    type(physics_ptend) :: ptend_all
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    real(r8) :: pblh_c(pcols), tpert_c(pcols), landfrac_c(pcols), mcon_c(pcols,pverp), pflx_c(pcols,pverp), cme_c(pcols,pver), &
+                zdu_c(pcols,pver), rliq_c(pcols), rice_c(pcols), jctop_c(pcols), jcbot_c(pcols), tmp(pcols, pverp)
+    real(r8), pointer :: f2(:,:), f3(:,:,:)
+    integer, pointer :: ip(:)
+    integer :: c0, nc, ic, m, j, ng, nl
+
+    pbuf => pbuf2d(:, 1)
+    ptend_lq(:) = 0
+    c0 = 0; ic = 0
+    do while (c0 < n)
+      nc = min(pcols, n - c0)
+      ic = ic + 1
+      call state_fill(state, c0, nc, t, u, v, pmid, pdel, rpdel, lnpmid, zm, pdeldry, pint, lnpint, zi, phis, ps)
+      do m = 1, pcnst
+        call put2(q(:,:,m), c0, nc, pver, state%q(:,:,m))
+      end do
+      call pbuf_zero(pbuf)
+      call pbuf_get_field(pbuf, cld_idx, f2, start=(/1,1,pbuf_old_tim_idx()/), kount=(/pcols,pver,1/))
+      call put2(cld, c0, nc, pver, f2)
+      call pbuf_get_field(pbuf, fracis_idx, f3)
+      do m = 1, pcnst
+        call put2(fracis(:,:,m), c0, nc, pver, f3(:,:,m))
+      end do
+      pblh_c = pad; tpert_c = pad; landfrac_c = pad
+      pblh_c(:nc) = pblh(c0+1:c0+nc); tpert_c(:nc) = tpert(c0+1:c0+nc); landfrac_c(:nc) = landfrac(c0+1:c0+nc)
+      cap_on = .true.; cap_n = 0
+
+      call zm_conv_tend(pblh_c, mcon_c, cme_c, tpert_c, pflx_c, zdu_c, rliq_c, rice_c, ztodt, jctop_c, jcbot_c, &
+                        state, ptend_all, landfrac_c, pbuf)
+
+      cap_on = .false.
+      if (allocated(ptend_all%s)) call get2(ptend_all%s, c0, nc, pver, ptend_s)
+      if (allocated(ptend_all%u)) call get2(ptend_all%u, c0, nc, pver, ptend_u)
+      if (allocated(ptend_all%v)) call get2(ptend_all%v, c0, nc, pver, ptend_v)
+      do m = 1, pcnst
+        if (ptend_all%lq(m)) then
+          ptend_lq(m) = 1
+          call get2(ptend_all%q(:,:,m), c0, nc, pver, ptend_q(:,:,m))
+        end if
+      end do
+      call get2(mcon_c, c0, nc, pverp, mcon); call get2(pflx_c, c0, nc, pverp, pflx)
+      call get2(cme_c, c0, nc, pver, cme);    call get2(zdu_c, c0, nc, pver, zdu)
+      rliq(c0+1:c0+nc) = rliq_c(:nc); rice(c0+1:c0+nc) = rice_c(:nc)
+      jctop(c0+1:c0+nc) = jctop_c(:nc); jcbot(c0+1:c0+nc) = jcbot_c(:nc)
+      call pbuf_get1(pbuf, 'PREC_DP', prec, c0, nc);      call pbuf_get1(pbuf, 'SNOW_DP', snow, c0, nc)
+      call pbuf_get2(pbuf, 'ICWMRDP', ql, c0, nc, pver);  call pbuf_get2(pbuf, 'RPRDDP', rprd, c0, nc, pver)
+      call pbuf_get2(pbuf, 'NEVAPR_DPCU', evapcdp, c0, nc, pver)
+      call pbuf_get2(pbuf, 'DLFZM', dlf, c0, nc, pver);   call pbuf_get2(pbuf, 'DIFZM', dif, c0, nc, pver)
+      call pbuf_get2(pbuf, 'CMFMC_DP', mconzm, c0, nc, pverp)
+      call pbuf_get2(pbuf, 'DP_FLXPRC', flxprec, c0, nc, pverp); call pbuf_get2(pbuf, 'DP_FLXSNW', flxsnow, c0, nc, pverp)
+      ! gathered set: lengath = count(ideep > 0) is how zm_conv_tend_2 recovers it (:993); slots beyond it were zeroed above
+      call pbuf_get_field(pbuf, pbuf_get_index('ZM_IDEEP'), ip)
+      ng = count(ip(1:pcols) > 0)
+      lengath(ic) = ng
+      call pbuf_get2(pbuf, 'ZM_MU', mu, c0, ng, pver); call pbuf_get2(pbuf, 'ZM_MD', md, c0, ng, pver)
+      call pbuf_get2(pbuf, 'ZM_DU', du, c0, ng, pver); call pbuf_get2(pbuf, 'ZM_EU', eu, c0, ng, pver)
+      call pbuf_get2(pbuf, 'ZM_ED', ed, c0, ng, pver); call pbuf_get2(pbuf, 'ZM_DP', dp, c0, ng, pver)
+      call pbuf_get1(pbuf, 'ZM_DSUBCLD', dsubcld, c0, ng)
+      call pbuf_geti(pbuf, 'ZM_JT', jt, c0, ng); call pbuf_geti(pbuf, 'ZM_MAXG', maxg, c0, ng); call pbuf_geti(pbuf, 'ZM_IDEEP', ideep, c0, ng)
+      do j = 1, n_hist_col
+        nl = outfld_captured(trim(hist_col(j)), pcols, tmp)
+        hcol(c0+1:c0+nc, j) = tmp(:nc, 1)
+      end do
+      do j = 1, n_hist_lev
+        nl = outfld_captured(trim(hist_lev(j)), pcols, tmp)
+        call get2(tmp(:, :pver), c0, nc, pver, hlev(:,:,j))
+      end do
+      do j = 1, n_hist_int
+        nl = outfld_captured(trim(hist_int(j)), pcols, tmp)
+        call get2(tmp, c0, nc, pverp, hint(:,:,j))
+      end do
+      call physics_ptend_dealloc(ptend_all)
+      call physics_state_dealloc(state)
+      c0 = c0 + nc
+    end do
+  end subroutine ref_zm_conv_tend
+
+  ! ---- zm_conv_tend_2 (zm_conv_intr.F90:955-1028) -----------------------------------------------------------
+  ! the ZM_* pbuf fields arrive as arguments (gathered layout, as ref_zm_conv_tend returned them)
+  subroutine ref_zm_conv_tend_2(n, ztodt, q, pdeldry, fracis, mu, md, du, eu, ed, dp, dsubcld, jt, maxg, ideep, ptend_q, ptend_lq) &
+       bind(C, name='ref_zm_conv_tend_2')
+    integer(c_int), value :: n
+    real(c_double), value :: ztodt
+    real(c_double), intent(in) :: q(pver,n,pcnst), pdeldry(pver,n), fracis(pver,n,pcnst), mu(pver,n), md(pver,n), du(pver,n), &
+                                  eu(pver,n), ed(pver,n), dp(pver,n), dsubcld(n)
+    integer(c_int), intent(in) :: jt(*), maxg(*), ideep(*)         ! n rounded up to whole chunks
+    real(c_double), intent(inout) :: ptend_q(pver,n,pcnst)
+    integer(c_int), intent(inout) :: ptend_lq(pcnst)
+    type(physics_state) :: state
+    type(physics_ptend) :: ptend
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    real(r8), pointer :: f3(:,:,:)
+    integer :: c0, nc, m
+    pbuf => pbuf2d(:, 1)
+    ptend_lq(:) = 0
+    c0 = 0
+    do while (c0 < n)
+      nc = min(pcols, n - c0)
+      ncols_of_chunk = nc
+      call physics_state_alloc(state, 1, pcols)
+      state%ncol = nc
+      do m = 1, pcnst
+        call put2(q(:,:,m), c0, nc, pver, state%q(:,:,m))
+      end do
+      call put2(pdeldry, c0, nc, pver, state%pdeldry)
+      call pbuf_zero(pbuf)
+      call pbuf_get_field(pbuf, fracis_idx, f3)
+      do m = 1, pcnst
+        call put2(fracis(:,:,m), c0, nc, pver, f3(:,:,m))
+      end do
+      call pbuf_put2(pbuf, 'ZM_MU', mu, c0, nc, pver); call pbuf_put2(pbuf, 'ZM_MD', md, c0, nc, pver)
+      call pbuf_put2(pbuf, 'ZM_DU', du, c0, nc, pver); call pbuf_put2(pbuf, 'ZM_EU', eu, c0, nc, pver)
+      call pbuf_put2(pbuf, 'ZM_ED', ed, c0, nc, pver); call pbuf_put2(pbuf, 'ZM_DP', dp, c0, nc, pver)
+      call pbuf_put1(pbuf, 'ZM_DSUBCLD', dsubcld, c0, nc)
+      call pbuf_puti(pbuf, 'ZM_JT', jt, c0); call pbuf_puti(pbuf, 'ZM_MAXG', maxg, c0); call pbuf_puti(pbuf, 'ZM_IDEEP', ideep, c0)
+
+      call zm_conv_tend_2(state, ptend, ztodt, pbuf)
+
+      do m = 1, pcnst
+        if (ptend%lq(m)) then
+          ptend_lq(m) = 1
+          call get2(ptend%q(:,:,m), c0, nc, pver, ptend_q(:,:,m))
+        end if
+      end do
+      call physics_ptend_dealloc(ptend)
+      call physics_state_dealloc(state)
+      c0 = c0 + nc
+    end do
+  end subroutine ref_zm_conv_tend_2
+
+  ! ---- convect_diagnostics_calc (convect_diagnostics.F90:115-249) ---------------------------------------------
+  ! pbuf in/out fields arrive and leave as arguments: CLDTOP / CLDBOT (cnt, cnb), RPRDDP, and the shallow scheme's
+  ! CMFMC_SH, RPRDSH, ICWMRSH, NEVAPR_SHCU, PREC_SH, SNOW_SH (the reference zeroes them: only CLUBB_SGS is supported, :76-78)
+  subroutine ref_convect_diagnostics_calc(n, ztodt, cmfmc, qc, rliq, pmid, cnt, cnb, rprddp, cmfmc2, rprdsh, icwmr, evapcsh, &
+       precc, snow, qc2, rliq2, rprdtot, pcnt, pcnb) bind(C, name='ref_convect_diagnostics_calc')
+    integer(c_int), value :: n
+    real(c_double), value :: ztodt
+    real(c_double), intent(inout) :: cmfmc(pverp,n), qc(pver,n), rliq(n), cnt(n), cnb(n), cmfmc2(pverp,n), rprdsh(pver,n), &
+                                     icwmr(pver,n), evapcsh(pver,n), precc(n), snow(n), qc2(pver,n), rliq2(n), rprdtot(pver,n), &
+                                     pcnt(n), pcnb(n)
+    real(c_double), intent(in) :: pmid(pver,n), rprddp(pver,n)
+    type(physics_state) :: state
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    real(r8) :: cmfmc_c(pcols,pverp), qc_c(pcols,pver), rliq_c(pcols), qc2_c(pcols,pver), rliq2_c(pcols), tmp(pcols,pverp)
+    integer :: c0, nc, nl
+    pbuf => pbuf2d(:, 1)
+    c0 = 0
+    do while (c0 < n)
+      nc = min(pcols, n - c0)
+      ncols_of_chunk = nc
+      call physics_state_alloc(state, 1, pcols)
+      state%ncol = nc
+      call put2(pmid, c0, nc, pver, state%pmid)
+      call pbuf_zero(pbuf)
+      call pbuf_put1(pbuf, 'CLDTOP', cnt, c0, nc);          call pbuf_put1(pbuf, 'CLDBOT', cnb, c0, nc)
+      call pbuf_put2(pbuf, 'RPRDDP', rprddp, c0, nc, pver); call pbuf_put2(pbuf, 'CMFMC_SH', cmfmc2, c0, nc, pverp)
+      call pbuf_put2(pbuf, 'RPRDSH', rprdsh, c0, nc, pver); call pbuf_put2(pbuf, 'ICWMRSH', icwmr, c0, nc, pver)
+      call pbuf_put2(pbuf, 'NEVAPR_SHCU', evapcsh, c0, nc, pver)
+      call pbuf_put1(pbuf, 'PREC_SH', precc, c0, nc);       call pbuf_put1(pbuf, 'SNOW_SH', snow, c0, nc)
+      cmfmc_c = pad; qc_c = pad; rliq_c = pad
+      call put2(cmfmc, c0, nc, pverp, cmfmc_c); call put2(qc, c0, nc, pver, qc_c)
+      rliq_c(:nc) = rliq(c0+1:c0+nc)
+      cap_on = .true.; cap_n = 0
+
+      call convect_diagnostics_calc(ztodt, cmfmc_c, qc_c, qc2_c, rliq_c, rliq2_c, state, pbuf)
+
+      cap_on = .false.
+      call get2(cmfmc_c, c0, nc, pverp, cmfmc); call get2(qc_c, c0, nc, pver, qc); call get2(qc2_c, c0, nc, pver, qc2)
+      rliq(c0+1:c0+nc) = rliq_c(:nc); rliq2(c0+1:c0+nc) = rliq2_c(:nc)
+      call pbuf_get1(pbuf, 'CLDTOP', cnt, c0, nc);           call pbuf_get1(pbuf, 'CLDBOT', cnb, c0, nc)
+      call pbuf_get2(pbuf, 'RPRDTOT', rprdtot, c0, nc, pver); call pbuf_get2(pbuf, 'CMFMC_SH', cmfmc2, c0, nc, pverp)
+      call pbuf_get2(pbuf, 'RPRDSH', rprdsh, c0, nc, pver);   call pbuf_get2(pbuf, 'ICWMRSH', icwmr, c0, nc, pver)
+      call pbuf_get2(pbuf, 'NEVAPR_SHCU', evapcsh, c0, nc, pver)
+      call pbuf_get1(pbuf, 'PREC_SH', precc, c0, nc);         call pbuf_get1(pbuf, 'SNOW_SH', snow, c0, nc)
+      nl = outfld_captured('PCLDTOP', pcols, tmp); pcnt(c0+1:c0+nc) = tmp(:nc, 1)
+      nl = outfld_captured('PCLDBOT', pcols, tmp); pcnb(c0+1:c0+nc) = tmp(:nc, 1)
+      call physics_state_dealloc(state)
+      c0 = c0 + nc
+    end do
+  end subroutine ref_convect_diagnostics_calc
+
+  ! ---- physics_update (physics_types.F90:210-497) ---------------------------------------------------------------
+  ! one parameterisation's tendencies applied to a state: flags = ls + 2 lq(1) + 4 lu + 8 lv; q is water vapour only here
+  ! (constituents 2..pcnst ride along untouched).  Returns the updated t, q, u, v and the zi, zm, s physics_update derives.
+  subroutine ref_physics_update(n, dt, flags, t, u, v, q, pmid, pdel, rpdel, lnpmid, pint, lnpint, phis, tend_s, tend_q, tend_u, tend_v, &
+       zi, zm, s) bind(C, name='ref_physics_update')
+    integer(c_int), value :: n, flags
+    real(c_double), value :: dt
+    real(c_double), intent(inout) :: t(pver,n), u(pver,n), v(pver,n), q(pver,n)
+    real(c_double), intent(in) :: pmid(pver,n), pdel(pver,n), rpdel(pver,n), lnpmid(pver,n), pint(pverp,n), lnpint(pverp,n), phis(n), &
+                                  tend_s(pver,n), tend_q(pver,n), tend_u(pver,n), tend_v(pver,n)
+    real(c_double), intent(inout) :: zi(pverp,n), zm(pver,n), s(pver,n)
+    type(physics_state) :: state
+    type(physics_ptend) :: ptend
+    logical :: lq(pcnst)
+    integer :: c0, nc
+    c0 = 0
+    do while (c0 < n)
+      nc = min(pcols, n - c0)
+      ncols_of_chunk = nc
+      call physics_state_alloc(state, 1, pcols)
+      state%ncol = nc
+      call put2(t, c0, nc, pver, state%t); call put2(u, c0, nc, pver, state%u); call put2(v, c0, nc, pver, state%v)
+      state%q(:nc, :, :) = 0._r8
+      call put2(q, c0, nc, pver, state%q(:,:,1))
+      call put2(pmid, c0, nc, pver, state%pmid); call put2(pdel, c0, nc, pver, state%pdel); call put2(rpdel, c0, nc, pver, state%rpdel)
+      call put2(lnpmid, c0, nc, pver, state%lnpmid); call put2(pint, c0, nc, pverp, state%pint); call put2(lnpint, c0, nc, pverp, state%lnpint)
+      state%phis(:nc) = phis(c0+1:c0+nc)
+      lq = .false.; lq(1) = iand(flags, 2) /= 0
+      call physics_ptend_init(ptend, pcols, 'zm_convr', ls=iand(flags, 1) /= 0, lu=iand(flags, 4) /= 0, lv=iand(flags, 8) /= 0, lq=lq)
+      if (ptend%ls) call put2(tend_s, c0, nc, pver, ptend%s)
+      if (ptend%lq(1)) call put2(tend_q, c0, nc, pver, ptend%q(:,:,1))
+      if (ptend%lu) call put2(tend_u, c0, nc, pver, ptend%u)
+      if (ptend%lv) call put2(tend_v, c0, nc, pver, ptend%v)
+
+      call physics_update(state, ptend, dt)
+
+      call get2(state%t, c0, nc, pver, t); call get2(state%u, c0, nc, pver, u); call get2(state%v, c0, nc, pver, v)
+      call get2(state%q(:,:,1), c0, nc, pver, q)
+      call get2(state%zi, c0, nc, pverp, zi); call get2(state%zm, c0, nc, pver, zm); call get2(state%s, c0, nc, pver, s)
+      call physics_state_dealloc(state)
+      c0 = c0 + nc
+    end do
+  end subroutine ref_physics_update
+
+  ! ---- the tail of d_p_coupling's derived-fields block (fv/dp_coupling.F90:630-657; that file needs the FV dycore and is
+  ! not compiled): the reference's own set_state_pdry and set_wet_to_dry (physics_types.F90:1925, :1968) and the three
+  ! qneg3 calls, in dp_coupling's order.  q(pver,n,pcnst) in/out; dry-pressure fields out.
+  subroutine ref_dp_coupling_dry_tail(n, pint, pdel, q, pdeldry, rpdeldry, pmiddry, lnpmiddry, pintdry, lnpintdry, psdry) &
+       bind(C, name='ref_dp_coupling_dry_tail')
+    integer(c_int), value :: n
+    real(c_double), intent(in) :: pint(pverp,n), pdel(pver,n)
+    real(c_double), intent(inout) :: q(pver,n,pcnst), pdeldry(pver,n), rpdeldry(pver,n), pmiddry(pver,n), lnpmiddry(pver,n), &
+                                     pintdry(pverp,n), lnpintdry(pverp,n), psdry(n)
+    type(physics_state) :: state
+    integer :: c0, nc, m
+    c0 = 0
+    do while (c0 < n)
+      nc = min(pcols, n - c0)
+      ncols_of_chunk = nc
+      call physics_state_alloc(state, 1, pcols)
+      state%ncol = nc
+      call put2(pint, c0, nc, pverp, state%pint); call put2(pdel, c0, nc, pver, state%pdel)
+      do m = 1, pcnst
+        call put2(q(:,:,m), c0, nc, pver, state%q(:,:,m))
+      end do
+      call set_state_pdry(state)                                                               ! dp_coupling.F90:636
+      call set_wet_to_dry(state)                                                               ! :637
+      call qneg3('D_P_COUPLING', 1, nc, pcols, pver, 1, pcnst, qmin, state%q)                  ! :644-645
+      m = 2                                                                                    ! ixcldliq
+      call qneg3('D_P_COUPLING/CLDLIQ', 1, nc, pcols, pver, m, m, qmin(m:m), state%q(:,:,m:m)) ! :646-648
+      m = 3                                                                                    ! ixcldice
+      call qneg3('D_P_COUPLING/CLDICE', 1, nc, pcols, pver, m, m, qmin(m:m), state%q(:,:,m:m)) ! :649-651
+      do m = 1, pcnst
+        call get2(state%q(:,:,m), c0, nc, pver, q(:,:,m))
+      end do
+      call get2(state%pdeldry, c0, nc, pver, pdeldry);     call get2(state%rpdeldry, c0, nc, pver, rpdeldry)
+      call get2(state%pmiddry, c0, nc, pver, pmiddry);     call get2(state%lnpmiddry, c0, nc, pver, lnpmiddry)
+      call get2(state%pintdry, c0, nc, pverp, pintdry);    call get2(state%lnpintdry, c0, nc, pverp, lnpintdry)
+      psdry(c0+1:c0+nc) = state%psdry(:nc)
+      call physics_state_dealloc(state)
+      c0 = c0 + nc
+    end do
+  end subroutine ref_dp_coupling_dry_tail
+
+end module ref_wrap_intr

@@ -35,6 +35,8 @@ contains
   end subroutine get_lw_spectral_boundaries
 end module radconstants
 
+#ifndef COLPHYS_REAL_PHYSICS_TYPES
+! (the "intr" oracle library compiles the reference's own physics_types.F90 and the physics_buffer of host_interfaces.F90)
 module physics_types
   ! the three components of physics_state (physics/physics_types.F90:62-121) modal_aer_opt reads
   use shr_kind_mod, only: r8 => shr_kind_r8
@@ -72,6 +74,7 @@ contains
     end if
   end subroutine get3d
 end module physics_buffer
+#endif
 
 module rad_constituents
   use shr_kind_mod,   only: r8 => shr_kind_r8
@@ -91,10 +94,10 @@ module rad_constituents
     module procedure info_list, info_mode, info_spec
   end interface rad_cnst_get_info
   interface rad_cnst_get_aer_mmr
-    module procedure mmr_mode
+    module procedure mmr_mode, mmr_bulk
   end interface rad_cnst_get_aer_mmr
   interface rad_cnst_get_aer_props
-    module procedure props_mode
+    module procedure props_mode, props_bulk
   end interface rad_cnst_get_aer_props
 contains
   subroutine rad_cnst_get_call_list(call_list)
@@ -127,6 +130,29 @@ contains
     real(r8), pointer :: mmr(:,:)
     mmr => mmr_store(:,:,l,m)
   end subroutine mmr_mode
+  ! bulk-aerosol and mode-number accessors: named by zm_conv_intr.F90:15-16 and used only under zmconv_microp (out of scope)
+  subroutine mmr_bulk(list_idx, m, state, pbuf, mmr)
+    integer, intent(in) :: list_idx, m
+    type(physics_state), intent(in), target :: state
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    real(r8), pointer :: mmr(:,:)
+    nullify(mmr)
+  end subroutine mmr_bulk
+  subroutine props_bulk(list_idx, iaer, aername, num_to_mass_aer)
+    integer, intent(in) :: list_idx, iaer
+    character(len=*), intent(out), optional :: aername
+    real(r8), intent(out), optional :: num_to_mass_aer
+    if (present(aername)) aername = ' '
+    if (present(num_to_mass_aer)) num_to_mass_aer = 0._r8
+  end subroutine props_bulk
+  subroutine rad_cnst_get_mode_num(list_idx, m, phase, state, pbuf, num)
+    integer, intent(in) :: list_idx, m
+    character(len=1), intent(in) :: phase
+    type(physics_state), intent(in), target :: state
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    real(r8), pointer :: num(:,:)
+    nullify(num)
+  end subroutine rad_cnst_get_mode_num
   subroutine props_mode(list_idx, m, l, density_aer, refindex_aer_sw, refindex_aer_lw, spectype, hygro_aer)
     integer, intent(in) :: list_idx, m, l
     real(r8), intent(out), optional :: density_aer, hygro_aer
@@ -276,10 +302,25 @@ end module modal_aero_calcsize
 
 module namelist_utils
 contains
+  ! positions unit u at the line that opens namelist group g (CAM's find_group_name); status 0 = found
   subroutine find_group_name(u, g, status)
     integer :: u, status
     character(len=*) :: g
+    character(len=256) :: line
+    integer :: ios
     status = 1
+    rewind(u, iostat=ios)
+    if (ios /= 0) return
+    do
+      read(u, '(a)', iostat=ios) line
+      if (ios /= 0) return
+      line = adjustl(line)
+      if (line(1:1) == '&' .and. trim(line(2:len_trim(g)+1)) == trim(g)) then
+        backspace(u)
+        status = 0
+        return
+      end if
+    end do
   end subroutine find_group_name
 end module namelist_utils
 

@@ -143,8 +143,14 @@ contains
 end module cam_history
 
 module constituents
+  use shr_kind_mod, only: r8 => shr_kind_r8
   integer, parameter :: pcnst = 40
   logical :: cnst_is_dry(pcnst) = .false.      ! set by the test driver (oracle/ref_wrap_zm.F90)
+  ! what the operator layer (physics_types.F90, zm_conv_intr.F90) reads; the test driver (oracle/ref_wrap_intr.F90) sets them
+  real(r8)          :: qmin(pcnst) = 0._r8
+  character(len=16) :: cnst_name(pcnst) = ' '
+  character(len=3)  :: cnst_type(pcnst) = 'wet'
+  logical :: cnst_is_convtran1(pcnst) = .false., cnst_is_convtran2(pcnst) = .false.
 contains
   function cnst_get_type_byind(m) result(t)
     integer, intent(in) :: m
@@ -152,16 +158,51 @@ contains
     t = 'wet'
     if (cnst_is_dry(m)) t = 'dry'
   end function cnst_get_type_byind
+  subroutine cnst_get_ind(name, ind, abort)
+    character(len=*), intent(in) :: name
+    integer, intent(out) :: ind
+    logical, intent(in), optional :: abort
+    integer :: m
+    ind = -1
+    do m = 1, pcnst
+      if (trim(cnst_name(m)) == trim(name)) ind = m
+    end do
+  end subroutine cnst_get_ind
+  subroutine cnst_add(name, mwc, cpc, qminc, ind, longname, readiv, mixtype, cam_outfld)
+    character(len=*), intent(in) :: name
+    real(r8), intent(in) :: mwc, cpc, qminc
+    integer, intent(out) :: ind
+    character(len=*), intent(in), optional :: longname, mixtype
+    logical, intent(in), optional :: readiv, cam_outfld
+    ind = -1
+  end subroutine cnst_add
 end module constituents
 
 module phys_grid
   use shr_kind_mod, only: r8 => shr_kind_r8
+  use ppgrid,       only: pcols
+  integer :: ncols_of_chunk = pcols              ! the test driver sets the chunk's column count before physics_state_alloc
 contains
   subroutine get_rlat_all_p(lchnk, n, rlat)
     integer, intent(in) :: lchnk, n
     real(r8), intent(out) :: rlat(n)
     rlat = 0._r8
   end subroutine get_rlat_all_p
+  subroutine get_rlon_all_p(lchnk, n, rlon)
+    integer, intent(in) :: lchnk, n
+    real(r8), intent(out) :: rlon(n)
+    rlon = 0._r8
+  end subroutine get_rlon_all_p
+  subroutine get_gcol_all_p(lchnk, n, gcols)
+    integer, intent(in) :: lchnk, n
+    integer, intent(out) :: gcols(n)
+    integer :: i
+    gcols = (/ (i, i = 1, n) /)
+  end subroutine get_gcol_all_p
+  integer function get_ncols_p(lchnk)
+    integer, intent(in) :: lchnk
+    get_ncols_p = ncols_of_chunk
+  end function get_ncols_p
   real(r8) function get_rlat_p(lchnk, icol)
     integer, intent(in) :: lchnk, icol
     get_rlat_p = 0._r8
@@ -173,18 +214,36 @@ contains
 end module phys_grid
 
 module phys_control
-  ! Only the two entry points the hot path touches (zm_conv.F90:263,871).  The reference's own
-  ! phys_control.F90 needs four more absent modules plus mpi_bcast (SURVEY.md Appendix A).
+  ! Only the entry points the hot path and its operator layer touch (zm_conv.F90:263,871; zm_conv_intr.F90:268,318,375;
+  ! physics_types.F90:16,283; convect_diagnostics.F90:57).  The reference's own phys_control.F90 needs four more absent
+  ! modules plus mpi_bcast (SURVEY.md Appendix A).
+  logical :: deepconv_pbl_off = .false.          ! phys_deepconv_pbl(): "no deep convection in the PBL"; set by the test driver
 contains
   logical function cam_physpkg_is(name)
     character(len=*), intent(in) :: name
     cam_physpkg_is = (trim(name) == 'cam_dev')
   end function cam_physpkg_is
-  subroutine phys_getopts(history_amwg_out, history_aero_optics_out, history_dust_out)
-    logical, intent(out), optional :: history_amwg_out, history_aero_optics_out, history_dust_out
+  logical function waccmx_is(name)
+    character(len=*), intent(in) :: name
+    waccmx_is = .false.
+  end function waccmx_is
+  logical function phys_deepconv_pbl()
+    phys_deepconv_pbl = deepconv_pbl_off
+  end function phys_deepconv_pbl
+  subroutine phys_getopts(history_amwg_out, history_aero_optics_out, history_dust_out, history_budget_out, &
+                          history_budget_histfile_num_out, state_debug_checks_out, shallow_scheme_out, dme_energy_adjust_out)
+    logical, intent(out), optional :: history_amwg_out, history_aero_optics_out, history_dust_out, history_budget_out
+    logical, intent(out), optional :: state_debug_checks_out, dme_energy_adjust_out
+    integer, intent(out), optional :: history_budget_histfile_num_out
+    character(len=16), intent(out), optional :: shallow_scheme_out
     if (present(history_amwg_out)) history_amwg_out = .false.
     if (present(history_aero_optics_out)) history_aero_optics_out = .false.
     if (present(history_dust_out)) history_dust_out = .false.
+    if (present(history_budget_out)) history_budget_out = .false.
+    if (present(history_budget_histfile_num_out)) history_budget_histfile_num_out = 1
+    if (present(state_debug_checks_out)) state_debug_checks_out = .false.      ! CAM's default (phys_control.F90)
+    if (present(shallow_scheme_out)) shallow_scheme_out = 'CLUBB_SGS'
+    if (present(dme_energy_adjust_out)) dme_energy_adjust_out = .false.
   end subroutine phys_getopts
 end module phys_control
 
@@ -201,8 +260,12 @@ end module dycore
 
 module air_composition
   ! water vapour only unless the test driver widens it (geopotential.F90:256-274)
+  use shr_kind_mod, only: r8 => shr_kind_r8
   integer :: thermodynamic_active_species_num = 1
   integer :: thermodynamic_active_species_idx(8) = (/1, 2, 3, 4, 5, 6, 7, 8/)
+  integer :: dry_air_species_num = 0
+  ! composition-dependent cp and R of dry air per chunk (physics_types.F90:12,393-409); allocated and filled by the test driver
+  real(r8), allocatable :: cpairv(:,:,:), rairv(:,:,:)
 end module air_composition
 
 module zm_microphysics
@@ -220,6 +283,11 @@ module zm_microphysics
     type(ptr2d), allocatable :: mmr_a(:,:)
     real(r8), allocatable :: numg_a(:,:,:), dgnumg(:,:,:), mmrg_bulk(:,:,:)
     real(r8), allocatable :: mmrg_a(:,:,:,:)
+    ! components zm_conv_intr.F90:1155-1290 (zm_aero_init, only reached under zmconv_microp) names
+    integer :: mode_accum_idx = -1, mode_aitken_idx = -1, mode_coarse_idx = -1, coarse_dust_idx = -1, coarse_nacl_idx = -1
+    integer :: idxsul = -1, idxdst1 = -1, idxdst2 = -1, idxdst3 = -1, idxdst4 = -1, idxbcphi = -1
+    real(r8) :: sigmag_aitken = 0._r8
+    real(r8), allocatable :: voltonumblo(:), voltonumbhi(:), specdens(:,:), spechygro(:,:), num_to_mass_aer(:)
   end type zm_aero_t
   type zm_conv_t
     real(r8), allocatable, dimension(:,:) :: frz, sprd, wu, qi, qliq, qice, qrain, qsnow, di, dnl, dni, &
@@ -244,4 +312,7 @@ contains
     type(zm_aero_t) :: aero
     stop 'zm_mphy: convective microphysics (zmconv_microp) is outside the hot-path scope'
   end subroutine zm_mphy
+  subroutine zm_mphyi()        ! zm_conv_intr.F90:1129 (zm_conv_micro_init, only under zmconv_microp)
+    stop 'zm_mphyi: convective microphysics (zmconv_microp) is outside the hot-path scope'
+  end subroutine zm_mphyi
 end module zm_microphysics

@@ -235,3 +235,121 @@ def aero_props_from_golden(g):
     if "m7" in g and int(g["m7"]):
         return synth.make_aero_props(int(g["seed"]), synth.NSPEC_M7, synth.SPECTYPE_M7)
     return synth.make_aero_props(int(g["seed"]))
+
+
+# ---- the operator layer: zm_conv_tend / zm_conv_tend_2 (zm_conv_intr.F90:390-1028) --------------------------------
+INTR_GOLDEN = ["intr_l32", "intr_l70"]
+
+
+def intr_state_from_golden(g):
+    st = {k[3:]: v for k, v in g.items() if k.startswith("in_") and k not in ("in_q6", "in_fracis6")}
+    st["q"] = g["in_q6"][0]
+    st["ncol"] = int(g["ncol"])
+    return st
+
+
+def zm_conv_tend_composed(o, st, q6, fracis6, lq1, isdry, dt, qmin=1.0e-12, pcols=PCOLS):
+    """zm_conv_tend (zm_conv_intr.F90:441-905) restated as a composition of the column routines of `o` (an oracle object:
+    zm_convr, zm_conv_evap, momtran, convtran, geopotential_t) with physics_update / physics_ptend_sum (physics_types.F90:292-340,
+    425-447, 698-844) in numpy between them.  Returns ptend_all, the pbuf fields and the outfld values under the golden's names."""
+    c = synth.PHYSCONST
+    cp, g_ = c["cpair"], c["gravit"]
+    n, pver = st["t"].shape
+    r = {}
+    z = o.zm_convr(st["t"], st["q"], st["pblh"], st["zm"], st["phis"], st["zi"], st["pmid"], st["pint"], st["pdel"], 0.5 * dt,
+                   st["tpert"], st["landfrac"])                                              # :662-675
+    for k in ("ql", "rprd", "dlf", "dif", "mu", "md", "du", "eu", "ed", "dp", "dsubcld", "jt", "maxg", "ideep", "lengath", "rliq", "rice",
+              "jctop", "jcbot", "cme", "zdu", "pflx"):
+        r[k] = z[k]
+    r["mcon"] = z["mcon"] * 100.0 / g_                                                        # :691-692
+    r["mconzm"] = r["mcon"]
+    h = {"CAPE": z["cape"], "EURT": z["eurt"][:, pver - 1], "CMFMC_DP": r["mcon"], "ZMDT": z["heat"] / cp, "ZMDQ": z["qtnd"],
+         "DIFZM": z["dif"], "DLFZM": z["dlf"]}
+    freq = np.zeros(n); mu_out = np.zeros((n, pver)); md_out = np.zeros((n, pver))
+    ps = st["pint"][:, -1]
+    pcont, pconb = ps.copy(), ps.copy()
+    for ic, lg in enumerate(z["lengath"]):                                                   # :685-688, 700-706, 722-729
+        for j in range(int(lg)):
+            row = ic * pcols + j
+            ii = ic * pcols + int(z["ideep"][row]) - 1
+            freq[ii] = 1.0
+            mu_out[ii] = z["mu"][row] * 100.0 / g_
+            md_out[ii] = z["md"][row] * 100.0 / g_
+            if z["maxg"][row] > z["jt"][row]:
+                pcont[ii] = st["pmid"][ii, z["jt"][row] - 1]
+                pconb[ii] = st["pmid"][ii, z["maxg"][row] - 1]
+    h.update(FREQZM=freq, ZMMU=mu_out, ZMMD=md_out, PCONVT=pcont, PCONVB=pconb)
+    # physics_update #1 (:737-739)
+    t1 = st["t"] + z["heat"] * dt / cp
+    q1 = np.maximum(st["q"] + z["qtnd"] * dt, qmin)
+    e = o.zm_conv_evap(t1, st["pmid"], st["pdel"], q1, st["landfrac"], z["rprd"], st["cld"], dt, z["prec"])      # :764-769
+    r.update(prec=e["prec"], snow=e["snow"], evapcdp=e["tend_q"], flxprec=e["flxprec"], flxsnow=e["flxsnow"])
+    h.update(EVAPTZM=e["tend_s"] / cp, FZSNTZM=e["tend_s_snwprd"] / cp, EVSNTZM=e["tend_s_snwevmlt"] / cp, EVAPQZM=e["tend_q"],
+             ZMFLXPRC=e["flxprec"], ZMFLXSNW=e["flxsnow"], ZMNTPRPD=e["ntprprd"], ZMNTSNPD=e["ntsnprd"], ZMEIHEAT=e["tend_s"],
+             PRECCDZM=e["prec"], PRECZ=e["prec"])
+    t2 = t1 + e["tend_s"] * dt / cp                                                           # :802-806
+    q2 = np.maximum(q1 + e["tend_q"] * dt, qmin)
+    m = o.momtran(st["u"], st["v"], z["mu"], z["md"], z["du"], z["eu"], z["ed"], z["dp"], z["dsubcld"], z["jt"], z["maxg"], z["ideep"],
+                  z["lengath"], dt)                                                          # :822-826 (winds = state1 u, v = state u, v)
+    h.update(ZMMTT=m["seten"] / cp, ZMMTU=m["dqdt"][0], ZMMTV=m["dqdt"][1], ZMUPGU=m["pguall"][0], ZMUPGD=m["pgdall"][0],
+             ZMVPGU=m["pguall"][1], ZMVPGD=m["pgdall"][1], ZMICUU=m["icwu"][0], ZMICUD=m["icwd"][0], ZMICVU=m["icwu"][1], ZMICVD=m["icwd"][1])
+    r["ptend_s"] = (z["heat"] + e["tend_s"]) + m["seten"]                                     # physics_ptend_sum x3
+    r["ptend_u"], r["ptend_v"] = m["dqdt"][0], m["dqdt"][1]
+    # convtran1 (:860-884): cloud liquid and ice of state1 (untouched by the three updates), moist mixing ratios, dpdry = 0
+    ncn = q6.shape[0]
+    do = np.zeros(ncn, np.int32); do[:] = np.asarray(lq1)[:ncn]
+    ct = o.convtran(q6, fracis6, z["mu"], z["md"], z["du"], z["eu"], z["ed"], z["dp"], np.ones_like(z["dp"]), z["jt"], z["maxg"], z["ideep"],
+                    z["lengath"], do, np.zeros(ncn, np.int32), dt)
+    pq = np.zeros_like(q6)
+    pq[0] = z["qtnd"] + e["tend_q"]
+    for mm in range(1, ncn):
+        if do[mm]:
+            pq[mm] = ct[mm]
+    r["ptend_q"] = pq
+    h.update(ZMDLIQ=ct[1], ZMDICE=ct[2])
+    r["state1"] = dict(t=t2 + m["seten"] * dt / cp, q=q2, u=st["u"] + m["dqdt"][0] * dt, v=st["v"] + m["dqdt"][1] * dt)
+    r["hist"] = h
+    return r
+
+
+def assert_tend_matches_golden(r, g, pcols=PCOLS, hist=True):
+    """r: zm_conv_tend_composed's dictionary (or an engine's outputs under the same names); g: an intr_* golden"""
+    from util import assert_close, gathered_mask
+    n = int(g["ncol"])
+    assert np.array_equal(r["lengath"], g["tend_lengath"])
+    m = gathered_mask(g["tend_lengath"], n, pcols)
+    for k in ("mu", "md", "du", "eu", "ed", "dp", "dsubcld", "jt", "maxg", "ideep"):
+        if k in r:
+            assert_close("zm_conv_tend." + k, r[k][m], g["tend_" + k][m])
+    for k in ("ptend_s", "ptend_u", "ptend_v", "mcon", "pflx", "cme", "zdu", "rliq", "rice", "jctop", "jcbot", "prec", "snow", "ql", "rprd",
+              "evapcdp", "dlf", "dif", "mconzm", "flxprec", "flxsnow"):
+        if k in r:
+            assert_close("zm_conv_tend." + k, r[k], g["tend_" + k])
+    if "ptend_q" in r:
+        for mm in range(r["ptend_q"].shape[0]):
+            assert bool(g["tend_ptend_lq"][mm]) == (mm < 3), mm
+            assert_close(f"zm_conv_tend.ptend_q[{mm}]", r["ptend_q"][mm], g["tend_ptend_q"][mm])
+    if hist:
+        for k, v in r["hist"].items():
+            assert_close("outfld " + k, v, g["hist_" + k])
+
+
+def dry_tail_numpy(pint, pdel, q, isdry, qmin):
+    """array-form restatement of set_state_pdry + set_wet_to_dry (physics_types.F90:1925-1984) + qneg3 as d_p_coupling calls them
+    (fv/dp_coupling.F90:636-651); q [ncnst][ncol][pver], water vapour first"""
+    n, pver = pdel.shape
+    pdeldry = pdel * (1.0 - q[0])
+    pintdry = np.empty((n, pver + 1)); pintdry[:, 0] = pint[:, 0]
+    psdry = pint[:, 0].copy()
+    pmiddry = np.empty((n, pver))
+    for k in range(pver):
+        pintdry[:, k + 1] = pintdry[:, k] + pdeldry[:, k]
+        pmiddry[:, k] = (pintdry[:, k + 1] + pintdry[:, k]) / 2.0
+        psdry = psdry + pdeldry[:, k]
+    qo = q.copy()
+    for m in range(q.shape[0]):
+        if isdry[m]:
+            qo[m] = q[m] * pdel / pdeldry
+        qo[m] = np.where(qo[m] < qmin[m], qmin[m], qo[m])
+    return dict(pdeldry=pdeldry, rpdeldry=1.0 / pdeldry, pmiddry=pmiddry, lnpmiddry=np.log(pmiddry), pintdry=pintdry,
+                lnpintdry=np.log(pintdry), psdry=psdry, q=qo)

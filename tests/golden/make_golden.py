@@ -154,6 +154,85 @@ def geo_dse_golden(ncol, pver, seed):
     return g
 
 
+def intr_inputs(ncol, pver, seed):
+    """Inputs of the operator-layer fixtures: soundings of which ~20 % convect (some cold enough for snow), six constituents
+    that matter -- water vapour, cloud liquid, cloud ice, three tracers, one of them of 'dry' type -- with insoluble fractions,
+    and the per-constituent tables the reference's constituents module would hold."""
+    st = synth.make_state(ncol, pver, seed, moist_boost=1.1)
+    rng = np.random.default_rng(seed + 41)
+    lev = np.linspace(0.0, 1.0, pver)[None, None, :]
+    q = np.empty((6, ncol, pver))
+    q[0] = st["q"]
+    q[1:] = rng.uniform(0.2, 1.0, (5, ncol, 1)) * 1.0e-6 * (0.05 + lev ** rng.uniform(0.5, 3.0, (5, ncol, 1)))
+    q[1:] *= 1.0 + 0.2 * rng.standard_normal((5, ncol, pver))
+    q[2, :, : pver // 3] = 0.0                                 # exact zeros: cloud ice absent aloft
+    q[4, ::7, pver // 2] *= -1.0                               # a few negative values: the minc < 0 branch of convtran
+    fracis = rng.uniform(0.0, 1.0, (6, ncol, pver))
+    pcnst = 40
+    isdry = np.zeros(pcnst, np.int32); isdry[4] = 1
+    lq1 = np.zeros(pcnst, np.int32); lq1[1:3] = 1              # cnst_is_convtran1: cloud liquid, cloud ice
+    lq2 = np.zeros(pcnst, np.int32); lq2[3:6] = 1              # cnst_is_convtran2: the three tracers
+    qmin = np.zeros(pcnst); qmin[0] = 1.0e-12
+    return st, np.ascontiguousarray(q), fracis, dict(isdry=isdry, lq1=lq1, lq2=lq2, qmin=qmin)
+
+
+def intr_golden(pver, ncol, seed):
+    """The reference's OPERATOR layer, compiled unmodified (oracle/Makefile ref_intr): zm_conv_tend and zm_conv_tend_2
+    (physics/zm_conv_intr.F90:390, :955) with physics_update / physics_ptend_sum / physics_state_copy of
+    physics/physics_types.F90 inside them, convect_diagnostics_calc (physics/convect_diagnostics.F90:115), physics_update on
+    its own, and the dry-mass tail of d_p_coupling's derived fields (set_state_pdry, set_wet_to_dry, qneg3)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    from ref_intr_oracle import HIST_COL, HIST_INT, HIST_LEV, RefIntrOracle
+    npool, ndeep = 8 * ncol, (2 * ncol) // 5
+    st, q, fracis, tab = intr_inputs(npool, pver, seed)
+    pe = synth.PTOP + synth.sigma_edges(pver) * (1.0e5 - synth.PTOP)
+    ro = RefIntrOracle(synth.ZM_NAMELIST, pe, PCOLS, pver, **tab)
+    # ~40 % convecting columns, none in the first chunk (zm_convr's early return, zm_conv.F90:917), a ragged last chunk
+    pre = ro.zm_conv_tend(st, synth.ZTODT, q=q, fracis=fracis)
+    sel = pick_columns(pre["hist"]["FREQZM"] > 0, ncol, ndeep, seed + 1)
+    st = subset(st, sel); q = np.ascontiguousarray(q[:, sel]); fracis = np.ascontiguousarray(fracis[:, sel])
+    g = {"seed": np.int64(seed), "ncol": np.int64(ncol), "pver": np.int64(pver), "in_q6": q, "in_fracis6": fracis}
+    for k in ("t", "u", "v", "pint", "pmid", "pdel", "rpdel", "lnpint", "lnpmid", "pdeldry", "phis", "pblh", "tpert", "landfrac", "cld",
+              "rair", "zvir", "zi", "zm"):
+        g["in_" + k] = st[k]
+    for k, v in tab.items():
+        g["tab_" + k] = v
+    o = ro.zm_conv_tend(st, synth.ZTODT, q=q, fracis=fracis)
+    for k, v in o.items():
+        if k in ("hist", "q_in", "fracis_in"):
+            continue
+        g["tend_" + k] = v[:6] if k == "ptend_q" else v
+    for k in HIST_COL + HIST_LEV + HIST_INT:
+        g["hist_" + k] = o["hist"][k]
+    pq, lq = ro.zm_conv_tend_2(q, st["pdeldry"], fracis, *[o[k] for k in ("mu", "md", "du", "eu", "ed", "dp", "dsubcld", "jt", "maxg", "ideep")],
+                               synth.ZTODT)
+    g["tend2_ptend_q"], g["tend2_lq"] = pq[:6], lq
+    f = cases.convect_diag_case(ncol, pver, seed + 3)
+    cd = ro.convect_diagnostics(f)
+    for k, v in cd.items():
+        g["cdiag_" + k] = v
+    # physics_update alone: tendencies large enough to push some water vapour below qmin (the qneg3 clip)
+    rng = np.random.default_rng(seed + 9)
+    ts = rng.normal(0.0, 2.0, (ncol, pver)); tq = rng.normal(0.0, 1.0e-9, (ncol, pver)) * (st["q"] / st["q"].max()) - 3.0 * st["q"] / synth.ZTODT * (rng.uniform(size=(ncol, pver)) < 0.02)
+    tu = rng.normal(0.0, 1.0e-3, (ncol, pver)); tv = rng.normal(0.0, 1.0e-3, (ncol, pver))
+    pu = ro.physics_update(st, synth.ZTODT, s=ts, q=tq, u=tu, v=tv)
+    g.update(pu_tend_s=ts, pu_tend_q=tq, pu_tend_u=tu, pu_tend_v=tv)
+    for k, v in pu.items():
+        g["pu_" + k] = v
+    pu2 = ro.physics_update(st, synth.ZTODT, u=tu, v=tv)          # winds only: no geopotential_t, zi / zm / s untouched (:435)
+    g["pu_uv_only_u"], g["pu_uv_only_t"] = pu2["u"], pu2["t"]
+    qd = q.copy()
+    qd[:, ::5, -3:] -= 2.0e-6 * (rng.uniform(size=qd[:, ::5, -3:].shape) < 0.5)   # negatives for qneg3 to clip
+    dt_ = ro.dp_coupling_dry_tail(st["pint"], st["pdel"], qd)
+    g["dry_in_q6"] = qd
+    for k, v in dt_.items():
+        g["dry_" + k] = v[:6] if k == "q" else v
+    return g
+
+
+INTR_CASES = {"intr_l32": (32, 90, 20261010), "intr_l70": (70, 42, 20261011)}
+
 # aero_m7: seven modes (the kernels' more-than-four-modes path), duplicate and untyped species in the partition
 AERO_CASES = {"aero_l32": (32, 24, 20261004), "aero_l70": (70, 8, 20261005), "aero_m7": (32, 12, 20261008, True)}
 
@@ -173,6 +252,12 @@ if __name__ == "__main__":
             g = geo_dse_golden(40, pver, 33)
             np.savez_compressed(os.path.join(HERE, f"geo_dse_l{pver}.npz"), **g)
             print(f"geo_dse_l{pver}: T range {g['fv_t'].min():.1f} .. {g['fv_t'].max():.1f} K")
+    for name in [w for w in (sys.argv[1:] or list(INTR_CASES)) if w in INTR_CASES]:
+        g = intr_golden(*INTR_CASES[name])
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **g)
+        print(f"{name}: {int(g['ncol'])} columns x L{int(g['pver'])}, {int(g['tend_lengath'].sum())} deep, snow max {g['tend_snow'].max():.3e}, "
+              f"ZMDLIQ max {np.abs(g['hist_ZMDLIQ']).max():.3e}, clipped q {(g['pu_q'] == 1e-12).sum()}, {os.path.getsize(path)/1e6:.2f} MB")
     for name in [w for w in which if w in CASES]:
         g = zm_golden(*CASES[name])
         path = os.path.join(HERE, name + ".npz")

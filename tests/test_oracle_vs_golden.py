@@ -182,3 +182,86 @@ def test_evap_snow_paths_vs_reference_golden():
     assert g["evap_snow"].max() > 0 and (g["evap_tend_s_snwevmlt"] != 0).any() and (g["evap_tend_s_snwprd"] != 0).any()
     for k, v in e.items():
         assert_close("zm_conv_evap." + k, v, g["evap_" + k])
+
+
+# ---------------------------------------------------------------------------------------------------
+# the operator layer: fixtures from the reference's own zm_conv_intr.F90 / physics_types.F90 / convect_diagnostics.F90
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", cases.INTR_GOLDEN)
+def test_zm_conv_tend_composition_vs_reference_operator_golden(name):
+    """zm_conv_tend (zm_conv_intr.F90:390-905) as the reference's own file computes it -- physics_state_copy, zm_convr,
+    physics_ptend_sum, physics_update (qneg3, geopotential_t), zm_conv_evap, momtran, convtran1, every outfld -- against the
+    composition of the C restatement's column routines that tests/ and the engine's colphys_zm_conv_tend_dev stand for"""
+    g = cases.load_golden(name)
+    pver = int(g["pver"])
+    co = COracle(cases.default_params(pver))
+    st = cases.intr_state_from_golden(g)
+    r = cases.zm_conv_tend_composed(co, st, g["in_q6"], g["in_fracis6"], g["tab_lq1"], g["tab_isdry"], synth.ZTODT)
+    cases.assert_tend_matches_golden(r, g)
+    assert g["tend_lengath"].sum() > 10 and g["tend_lengath"][0] == 0
+    assert np.abs(g["tend_ptend_q"][1]).max() > 0 and np.abs(g["tend_ptend_q"][2]).max() > 0 and not g["tend_ptend_q"][3:].any()
+    assert (g["tend_ptend_lq"][:6] == [1, 1, 1, 0, 0, 0]).all()
+    assert np.array_equal(g["hist_CMFMC_DP"], g["tend_mconzm"]) and np.array_equal(g["hist_EVAPQZM"], g["tend_evapcdp"])
+
+
+@pytest.mark.parametrize("name", cases.INTR_GOLDEN)
+def test_zm_conv_tend_2_vs_reference_operator_golden(name):
+    """zm_conv_tend_2 (:955-1028): lengath = count(ideep > 0), dpdry gathered from state%pdeldry / 100, convtran of the
+    cnst_is_convtran2 constituents (one of them 'dry')"""
+    g = cases.load_golden(name)
+    pver, n = int(g["pver"]), int(g["ncol"])
+    co = COracle(cases.default_params(pver))
+    lq2, isdry = g["tab_lq2"][:6], g["tab_isdry"][:6]
+    assert (g["tend2_lq"][:6] == lq2).all() and not g["tend2_lq"][6:].any() and isdry[4]
+    lg, ideep = g["tend_lengath"], g["tend_ideep"]
+    dpdry = np.ones((n, pver))
+    for c in range(len(lg)):
+        for j in range(int(lg[c])):
+            dpdry[c * 16 + j] = g["in_pdeldry"][c * 16 + ideep[c * 16 + j] - 1] / 100.0
+    ct = co.convtran(g["in_q6"], g["in_fracis6"], *[g["tend_" + k] for k in ("mu", "md", "du", "eu", "ed", "dp")], dpdry,
+                     g["tend_jt"], g["tend_maxg"], ideep, lg, lq2.astype(np.int32), isdry.astype(np.int32), synth.ZTODT)
+    for m in range(6):
+        if lq2[m]:
+            assert np.abs(g["tend2_ptend_q"][m]).max() > 0
+            assert_close(f"zm_conv_tend_2.ptend_q[{m}]", ct[m], g["tend2_ptend_q"][m])
+        else:
+            assert not g["tend2_ptend_q"][m].any()
+
+
+@pytest.mark.parametrize("name", cases.INTR_GOLDEN)
+def test_convect_diagnostics_vs_reference_operator_golden(name):
+    """convect_diagnostics_calc (convect_diagnostics.F90:115-249; only the CLUBB_SGS branch exists, :76-78) from the
+    reference's own file: the C restatement bit for bit"""
+    g = cases.load_golden(name)
+    pver, n = int(g["pver"]), int(g["ncol"])
+    co = COracle(cases.default_params(pver))
+    f = cases.convect_diag_case(n, pver, int(g["seed"]) + 3)
+    o = co.convect_diagnostics({k: v.copy() for k, v in f.items()}, True)
+    for k in ("cmfmc", "qc", "rliq", "cnt", "cnb", "rprdtot", "pcnt", "pcnb", "cmfmc2", "rprdsh", "icwmr", "evapcsh", "precc", "snow"):
+        assert np.array_equal(o[k], g["cdiag_" + k]), k
+    assert not g["cdiag_qc2"].any() and not g["cdiag_rliq2"].any()
+
+
+@pytest.mark.parametrize("name", cases.INTR_GOLDEN)
+def test_physics_update_and_dry_tail_restatements_vs_reference_operator_golden(name):
+    """physics_update (physics_types.F90:210-497: tendencies applied, qneg3 clip at qmin, geopotential_t, dry static energy) and
+    the dry-mass tail of d_p_coupling's derived fields (set_state_pdry :1925, set_wet_to_dry :1968, qneg3;
+    fv/dp_coupling.F90:630-657) from the reference's own file against their array-form restatements"""
+    g = cases.load_golden(name)
+    pver = int(g["pver"])
+    co = COracle(cases.default_params(pver))
+    st = cases.intr_state_from_golden(g)
+    c, dt = synth.PHYSCONST, synth.ZTODT
+    t = st["t"] + g["pu_tend_s"] * dt / c["cpair"]
+    q = np.maximum(st["q"] + g["pu_tend_q"] * dt, 1.0e-12)
+    assert np.array_equal(t, g["pu_t"]) and np.array_equal(q, g["pu_q"]) and (q == 1.0e-12).sum() > 10
+    assert np.array_equal(st["u"] + g["pu_tend_u"] * dt, g["pu_u"]) and np.array_equal(st["v"] + g["pu_tend_v"] * dt, g["pu_v"])
+    zi, zm = co.geopotential_t(*cases.geo_args(st)[:6], t, q, st["rair"], c["gravit"], st["zvir"])
+    assert np.array_equal(zi, g["pu_zi"]) and np.array_equal(zm, g["pu_zm"])
+    assert np.array_equal(t * c["cpair"] + c["gravit"] * zm + st["phis"][:, None], g["pu_s"])
+    assert np.array_equal(g["pu_uv_only_u"], g["pu_u"]) and np.array_equal(g["pu_uv_only_t"], st["t"])
+    r = cases.dry_tail_numpy(st["pint"], st["pdel"], g["dry_in_q6"], g["tab_isdry"][:6], g["tab_qmin"][:6])
+    for k, v in r.items():
+        ref = g["dry_" + k]
+        assert_close("dry tail " + k, v, ref, rtol=1e-15)
+    assert (g["dry_q"][4] != g["dry_in_q6"][4]).any() and (g["dry_q"] >= 0).all() and (g["dry_in_q6"] < 0).any()
