@@ -117,6 +117,13 @@ class DerivedFieldsIO(C.Structure):
     _fields_ = [(n, PD) for n in DERIVED_FIELDS_IN + tuple(DERIVED_FIELDS_OUT)]
 
 
+DRY_MASS_OUT = {"pdeldry": 1, "rpdeldry": 1, "pmiddry": 1, "lnpmiddry": 1, "pintdry": 2, "lnpintdry": 2, "psdry": 0}
+
+
+class DryMassIO(C.Structure):
+    _fields_ = [("pint", PD), ("pdel", PD), ("q", PD), ("isdry", PI), ("qmin", PD)] + [(n, PD) for n in DRY_MASS_OUT]
+
+
 CONVECT_DIAG_FIELDS = ("cmfmc", "qc", "rliq", "cnt", "cnb", "cmfmc2", "qc2", "rprdsh", "rliq2", "cnt2", "cnb2", "precc", "snow",
                        "icwmr", "evapcsh", "rprddp", "pmid", "rprdtot", "pcnt", "pcnb")
 
@@ -146,6 +153,9 @@ ZM_TEND_OUT = {
 ZM_TEND_OUT_I = {"jt": 0, "maxg": 0, "ideep": 0, "lengath": 3}
 ZM_TEND_DIAG = {"freqzm": 0, "pcont": 0, "pconb": 0, "mu_out": 1, "md_out": 1}
 ZM_TEND_STATE1 = {"t1": 1, "q1": 1, "u1": 1, "v1": 1, "zi1": 2, "zm1": 1}
+# ABI 4: zm_conv_tend's remaining intent(out) arguments and what it hands to outfld (4 = [2][ncol][pver], u and v)
+ZM_TEND_HIST = {"cme": 1, "zdu": 1, "dif": 1, "eurt": 1, "pflx": 2, "zmdt_s": 1, "zmdq": 1, "evap_s": 1, "evap_s_snwprd": 1,
+                "evap_s_snwevmlt": 1, "ntprprd": 1, "ntsnprd": 1, "seten": 1, "pguall": 4, "pgdall": 4, "icwu": 4, "icwd": 4}
 
 
 class ZmConvTendIO(C.Structure):
@@ -156,6 +166,7 @@ class ZmConvTendIO(C.Structure):
         + [(n, PD) for n in ZM_TEND_DIAG]
         + [(n, PD) for n in ZM_TEND_STATE1]
         + [("status", PI)]
+        + [(n, PD) for n in ZM_TEND_HIST]
     )
 
 

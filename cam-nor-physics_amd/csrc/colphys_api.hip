@@ -477,6 +477,20 @@ int colphys_derived_fields_dev(int ncol, int pver, int ncnst, int dycore_kind, i
     return rc ? fail(rc, "derived_fields launch failed") : COLPHYS_OK;
 }
 
+int colphys_dry_mass_fields_dev(int ncol, int pver, int ncnst, const colphys_dry_mass_io *io, void *stream)
+{
+    int rc;
+    if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
+    if (!io) return fail(COLPHYS_ERR_ARG, "null io");
+    if (ncnst < 1) return fail(COLPHYS_ERR_ARG, "need ncnst >= 1 (water vapour first)");
+    const void *need[] = {io->pint, io->pdel, io->q, io->isdry, io->qmin, io->pdeldry, io->rpdeldry, io->pmiddry, io->lnpmiddry,
+                          io->pintdry, io->lnpintdry, io->psdry};
+    for (const void *p : need)
+        if (!p) return fail(COLPHYS_ERR_ARG, "null pointer in colphys_dry_mass_io");
+    rc = launch_dry_mass_fields(ncol, pver, ncnst, *io, (hipStream_t)stream);
+    return rc ? fail(rc, "dry_mass_fields launch failed") : COLPHYS_OK;
+}
+
 int colphys_convect_diagnostics_dev(int ncol, int pver, int shallow_is_clubb, const colphys_convect_diag_io *io, void *stream)
 {
     int rc;
@@ -539,14 +553,15 @@ int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dy
     if (g_tend_arena.reserve(bytes)) return fail(COLPHYS_ERR_HIP, "work-array allocation failed");
     Carver w(g_tend_arena.p);
     lk.unlock();
-    double *heat = w.take<double>(nM), *qtnd = w.take<double>(nM), *cme = w.take<double>(nM), *zdu = w.take<double>(nM),
-           *dif = w.take<double>(nM), *dnlf = w.take<double>(nM), *dnif = w.take<double>(nM), *eurt = w.take<double>(nM),
-           *mcon = w.take<double>(nI), *pflx = w.take<double>(nI);
-    double *tend_s = w.take<double>(nM), *snwprd = w.take<double>(nM), *snwevmlt = w.take<double>(nM), *tend_q = io->evapcdp,
-           *ntprprd = w.take<double>(nM), *ntsnprd = w.take<double>(nM);
-    double *wtend = w.take<double>(2 * nM), *pguall = w.take<double>(2 * nM),
-           *pgdall = w.take<double>(2 * nM), *icwu = w.take<double>(2 * nM), *icwd = w.take<double>(2 * nM),
-           *seten = w.take<double>(nM);
+    // (a work array the caller asked for by name -- ABI 4 history outputs -- lives in the caller's buffer instead)
+    auto mid = [&](double *user, size_t n) { return user ? user : w.take<double>(n); };
+    double *heat = mid(io->zmdt_s, nM), *qtnd = mid(io->zmdq, nM), *cme = mid(io->cme, nM), *zdu = mid(io->zdu, nM),
+           *dif = mid(io->dif, nM), *dnlf = w.take<double>(nM), *dnif = w.take<double>(nM), *eurt = mid(io->eurt, nM),
+           *mcon = w.take<double>(nI), *pflx = mid(io->pflx, nI);
+    double *tend_s = mid(io->evap_s, nM), *snwprd = mid(io->evap_s_snwprd, nM), *snwevmlt = mid(io->evap_s_snwevmlt, nM),
+           *tend_q = io->evapcdp, *ntprprd = mid(io->ntprprd, nM), *ntsnprd = mid(io->ntsnprd, nM);
+    double *wtend = w.take<double>(2 * nM), *pguall = mid(io->pguall, 2 * nM), *pgdall = mid(io->pgdall, 2 * nM),
+           *icwu = mid(io->icwu, 2 * nM), *icwd = mid(io->icwd, 2 * nM), *seten = mid(io->seten, nM);
     double *t1 = io->t1 ? io->t1 : w.take<double>(nM), *q1 = io->q1 ? io->q1 : w.take<double>(nM);
     double *u1 = io->u1 ? io->u1 : w.take<double>(nM), *v1 = io->v1 ? io->v1 : w.take<double>(nM);
     double *zi1 = io->zi1 ? io->zi1 : w.take<double>(nI), *zm1 = io->zm1 ? io->zm1 : w.take<double>(nM);

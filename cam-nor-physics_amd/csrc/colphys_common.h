@@ -357,6 +357,7 @@ int launch_math_probe(int kind, int64_t n, const double *x, double *y, hipStream
 int launch_convect_diag(int ncol, int pver, int clubb, const colphys_convect_diag_io &io, hipStream_t st);
 int launch_derived_fields(int ncol, int pver, int ncnst, int dycore_kind, int nspecies, double gravit,
                           const colphys_derived_fields_io &io, hipStream_t st);
+int launch_dry_mass_fields(int ncol, int pver, int ncnst, const colphys_dry_mass_io &io, hipStream_t st);
 // pdeldry: null (io.dpdry is the gathered dry pressure thickness) or state%pdeldry [ncol][pver] in Pa, gathered through ideep on the fly
 // ws_rows [ncol], ws_count [1], ws_il2g [nchunks]: device scratch (gathered-row list of the launch)
 int launch_convtran(int ncol, int pver, int pcols, int ncnst, const colphys_convtran_io &io, hipStream_t st, const double *pdeldry,

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
 
     const double mass = io.pdeldry[cc] * A.rga;        // :644 / :1300
     int bad = 0;                                       // units of this cell outside the sanity range of the optical depth (nerr_dopaer)
-    unsigned long long negm = 0;                       // lanes that met one <= -1e-10 (the reference halts below -1e-10; exactly -1e-10, which it only counts, is reported as negative too): wave-uniform, in SGPRs
+    unsigned long long negm = 0;                       // lanes that met one < -1e-10, where the reference halts (:1024, :1431; exactly -1e-10 is only counted, :997): wave-uniform, in SGPRs
     __syncthreads();
     int cur = 0;
 
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
                 pabs = fmin(pext, pabs);
                 const double dopaer = pext * mass;
                 const double dw = (pext - pabs) * mass;                 // dopaer*palb without the quotient (see the bands-outer kernel)
-                { const bool lo = dopaer <= -1.e-10, hi = dopaer >= 30.0; negm |= __ballot(lo); bad += (lo | hi) ? 1 : 0; }       // :997
+                { const bool lo = dopaer <= -1.e-10, hi = dopaer >= 30.0; negm |= __ballot(dopaer < -1.e-10); bad += (lo | hi) ? 1 : 0; }       // :997
                 if (VIS && ib == A.idx_sw_diag - 1 && live) {                     // hand-over to the diagnostics kernel
                     double *vo = io.vis_optics + (size_t)m * F + cc;
                     vo[0] = pext; vo[(size_t)A.nmodes * F] = pabs; vo[2 * (size_t)A.nmodes * F] = pasm;
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(NT, AERO_MIN_WAVES) void modal_aero_kernel(AeroDev 
                 pabs = pabs * wetvol * A.rhoh2o;
                 pabs = fmax(0.0, pabs);
                 const double dopaer = pabs * mass;
-                { const bool lo = dopaer <= -1.e-10, hi = dopaer >= 20.0; negm |= __ballot(lo); bad += (lo | hi) ? 1 : 0; }       // :1402
+                { const bool lo = dopaer <= -1.e-10, hi = dopaer >= 20.0; negm |= __ballot(dopaer < -1.e-10); bad += (lo | hi) ? 1 : 0; }       // :1402
                 s_acc[(size_t)jb * NT + threadIdx.x] = s_acc[(size_t)jb * NT + threadIdx.x] + dopaer;   // :1441
             }
             __syncthreads();
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
 
     const double mass = io.pdeldry[cc] * A.rga;        // :644 / :1300
     int bad = 0;                                       // units of this cell outside the sanity range of the optical depth (nerr_dopaer)
-    unsigned long long negm = 0;                       // lanes that met one <= -1e-10 (the reference halts below -1e-10; exactly -1e-10, which it only counts, is reported as negative too): wave-uniform, in SGPRs
+    unsigned long long negm = 0;                       // lanes that met one < -1e-10, where the reference halts (:1024, :1431; exactly -1e-10 is only counted, :997): wave-uniform, in SGPRs
 
     double cheb[NMMAX][NC], watervol[NMMAX], wetvol[NMMAX], wetinv[NMMAX], radsurf[NMMAX];
     // species counts: scalar loads, once.  (Read as A.nspec[m] inside the band loop they were VECTOR loads of a uniform
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
                     // below that both are < 1e-40 * mass.  A division sequence less per (band, mode) unit.
                     const double dopaer = pext * mass;
                     const double dw = (pext - pabs) * mass;
-                    { const bool lo = dopaer <= -1.e-10, hi = dopaer >= 30.0; negm |= __ballot(lo); bad += (lo | hi) ? 1 : 0; }
+                    { const bool lo = dopaer <= -1.e-10, hi = dopaer >= 30.0; negm |= __ballot(dopaer < -1.e-10); bad += (lo | hi) ? 1 : 0; }
                     if (VIS && ib == A.idx_sw_diag - 1) {                         // hand-over to the diagnostics kernel (uniform test):
                         hv0 = pext; hv1 = pabs; hv2 = pasm; hm = m;               // stored behind this unit's barrier, see above
                     }
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(NT, SW ? AERO_SW_WAVES : AERO_LW_WAVES) void modal_
                     pabs = pabs * wetvol[m] * A.rhoh2o;
                     pabs = fmax(0.0, pabs);
                     const double dopaer = pabs * mass;
-                    { const bool lo = dopaer <= -1.e-10, hi = dopaer >= 20.0; negm |= __ballot(lo); bad += (lo | hi) ? 1 : 0; }   // :1402
+                    { const bool lo = dopaer <= -1.e-10, hi = dopaer >= 20.0; negm |= __ballot(dopaer < -1.e-10); bad += (lo | hi) ? 1 : 0; }   // :1402
                     a0 = a0 + dopaer;                                   // :1441
                 }
                 __syncthreads();

@@ -689,11 +689,6 @@ int launch_convtran(int ncol, int pver, int pcols, int ncnst, const colphys_conv
     auto lanes_per_row = [](int n) { int p = 8; while (p < n) p <<= 1; return p > 64 ? 64 : p; };
     auto lds_bytes = [&](int ntp) { return (2 * (size_t)pver * 64 + (size_t)(64 / ntp) * 7 * pver) * sizeof(double); };
     if (lds_bytes(64) > 160 * 1024) return COLPHYS_ERR_UNSUPPORTED;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void *)convtran_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
     const int nchunks = (ncol + pcols - 1) / pcols;
     ConvtranList tl;
     tl.n = 0;
@@ -705,6 +700,9 @@ int launch_convtran(int ncol, int pver, int pcols, int ncnst, const colphys_conv
             int ntp = lanes_per_row(tl.n);
             while (ntp < 64 && lds_bytes(ntp) > 160 * 1024) ntp <<= 1;          // long profiles: fewer rows per wave
             const size_t lds = lds_bytes(ntp);
+            // per launch, not once per process: the attribute belongs to the CURRENT device's copy of the kernel, and
+            // colphys_finalize / colphys_init may have moved the engine to another one
+            if (set_lds((const void *)convtran_wave_kernel, lds)) return COLPHYS_ERR_HIP;
             int per_cu = (int)((160 * 1024) / (lds + 256));
             per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
             const int nper = ncol < 256 * per_cu ? ncol : 256 * per_cu;         // persistent waves over the gathered rows
@@ -789,6 +787,99 @@ int launch_derived_fields(int ncol, int pver, int ncnst, int dycore_kind, int ns
                                    io.rair, gravit, io.zvir, io.zi, io.zm, st);
     if (rc) return rc;
     hipLaunchKernelGGL(derived_dse_kernel, dim3(blocks), dim3(256), 0, st, ncol, pver, gravit, io.cpair, io.t, io.zm, io.phis, io.s);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}
+
+// ---- the dry-mass tail of d_p_coupling's derived fields (fv/dp_coupling.F90:630-651) ---------------------------------
+// set_state_pdry (physics_types.F90:1925-1964): a top-down running sum per column.  Same tiling as geopotential_t: the
+// element-wise part (pdeldry, its reciprocal) by all threads over the block's [GT columns][pver] slab, the sum by one lane per
+// column in LDS (odd row stride), the interface / mid-point fields and their logarithms stored coalesced.
+// set_wet_to_dry (:1968-1984) + qneg3 (dp_coupling.F90:644-651): element-wise over every constituent, grid-stride.
+namespace {
+__global__ __launch_bounds__(GNT) void dry_mass_scan_kernel(int ncol, int pver, const double *__restrict__ pint, const double *__restrict__ pdel,
+                                                          const double *__restrict__ qv, double *__restrict__ pdeldry,
+                                                          double *__restrict__ rpdeldry, double *__restrict__ pmiddry,
+                                                          double *__restrict__ lnpmiddry, double *__restrict__ pintdry,
+                                                          double *__restrict__ lnpintdry, double *__restrict__ psdry)
+{
+    extern __shared__ double smem[];
+    const int col0 = blockIdx.x * GT;
+    const int nc = min(GT, ncol - col0);
+    const int pverp = pver + 1, ldp = ldk_of(pverp);
+    const size_t L = (size_t)pver, LP = (size_t)pverp;
+    double *sI = smem;                    // [GT][ldp]: pintdry(k)
+    double *sD = smem + GT * ldp;         // [GT][ldp]: pdeldry(k), then pmiddry(k)
+    const int n = nc * pver;
+    for (int i = threadIdx.x; i < n; i += GNT) {
+        const int c = i / pver, k = i - c * pver;
+        const size_t g = col0 * L + i;
+        const double d = pdel[g] * (1.0 - qv[g]);                              // :1948
+        pdeldry[g] = d;
+        rpdeldry[g] = 1.0 / d;                                                 // :1956
+        sD[c * ldp + k] = d;
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < nc) {
+        double p = pint[(size_t)(col0 + c) * LP];                              // :1945-1946
+        double ps = p;
+        sI[c * ldp] = p;
+#pragma unroll SCAN_UNROLL
+        for (int k = 0; k < pver; ++k) {
+            const double d = sD[c * ldp + k];
+            const double pn = p + d;                                           // :1952
+            sI[c * ldp + k + 1] = pn;
+            sD[c * ldp + k] = (pn + p) / 2.0;                                  // :1953
+            ps = ps + d;                                                       // :1954
+            p = pn;
+        }
+        psdry[col0 + c] = ps;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc * pverp; i += GNT) {
+        const int cc = i / pverp, k = i - cc * pverp;
+        const double v = sI[cc * ldp + k];
+        pintdry[col0 * LP + i] = v;
+        lnpintdry[col0 * LP + i] = cp_log(v);                                  // :1958
+    }
+    for (int i = threadIdx.x; i < n; i += GNT) {
+        const int cc = i / pver, k = i - cc * pver;
+        const double v = sD[cc * ldp + k];
+        pmiddry[col0 * L + i] = v;
+        lnpmiddry[col0 * L + i] = cp_log(v);                                   // :1957
+    }
+}
+
+struct DryTab { double qmin[DF_MAXC]; unsigned char dry[DF_MAXC]; };
+__global__ void wet_to_dry_qneg_kernel(int ncol, int pver, int m0, int nm, DryTab tab, const double *__restrict__ pdel,
+                                       const double *__restrict__ pdeldry, double *q)
+{
+    const size_t F = (size_t)ncol * pver, n = (size_t)nm * F, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const size_t mm = i / F, g = i - mm * F;
+        double v = q[(size_t)m0 * F + i];
+        if (tab.dry[mm]) v = v * pdel[g] / pdeldry[g];                          // physics_types.F90:1979-1981
+        if (v < tab.qmin[mm]) v = tab.qmin[mm];                                // qneg3
+        q[(size_t)m0 * F + i] = v;
+    }
+}
+}  // namespace
+
+int launch_dry_mass_fields(int ncol, int pver, int ncnst, const colphys_dry_mass_io &io, hipStream_t st)
+{
+    const int ldp = ((pver + 1) & 1) ? pver + 1 : pver + 2;
+    const size_t lds = (size_t)GT * 2 * ldp * sizeof(double);
+    if (set_lds((const void *)dry_mass_scan_kernel, lds)) return COLPHYS_ERR_HIP;
+    hipLaunchKernelGGL(dry_mass_scan_kernel, dim3((ncol + GT - 1) / GT), dim3(GNT), lds, st, ncol, pver, io.pint, io.pdel, io.q, io.pdeldry,
+                       io.rpdeldry, io.pmiddry, io.lnpmiddry, io.pintdry, io.lnpintdry, io.psdry);
+    for (int m0 = 0; m0 < ncnst; m0 += DF_MAXC) {
+        DryTab tab;
+        const int nm = ncnst - m0 < DF_MAXC ? ncnst - m0 : DF_MAXC;
+        for (int m = 0; m < nm; ++m) { tab.qmin[m] = io.qmin[m0 + m]; tab.dry[m] = io.isdry[m0 + m] ? 1 : 0; }
+        const size_t n = (size_t)nm * ncol * pver;
+        const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(wet_to_dry_qneg_kernel, dim3(blocks), dim3(256), 0, st, ncol, pver, m0, nm, tab, io.pdel, io.pdeldry, io.q);
+    }
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
 

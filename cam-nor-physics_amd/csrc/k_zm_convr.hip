@@ -1540,11 +1540,18 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     // one wave per group doing both sweeps once the groups fill the SIMDs on their own (measured with the optics
     // running beside it: 48 602 columns 2.93 vs 3.01 ms, 97 202 columns 5.21 vs 5.26, 194 402 columns 10.24 vs 10.02,
     // 777 602 columns 41.7 vs 39.0).  COLPHYS_TRIG_MODE = 1 / 2 forces paired / fused (experiments).
-    static int n_simd = 0;
-    if (!n_simd) {
+    // SIMD count of the CURRENT device (cached per device index: the engine may be re-initialised on another one)
+    static int simd_of_dev[64] = {0};
+    int n_simd = 1024;
+    {
         int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        n_simd = 4 * cus;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (!simd_of_dev[dev]) {
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                simd_of_dev[dev] = 4 * cus;
+            }
+            n_simd = simd_of_dev[dev];
+        }
     }
     bool paired = nblk <= n_simd;
     if (const char *e = getenv("COLPHYS_TRIG_MODE")) {

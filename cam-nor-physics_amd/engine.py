@@ -65,7 +65,7 @@ EXPORTED_SYMBOLS = [
     "colphys_zm_conv_evap_dev", "colphys_zm_conv_evap_chunks",
     "colphys_momtran_dev", "colphys_momtran_chunks",
     "colphys_convtran_dev", "colphys_convtran_chunks", "colphys_physics_update_dev", "colphys_zm_conv_tend_dev",
-    "colphys_zm_conv_tend_2_dev", "colphys_convect_diagnostics_dev", "colphys_derived_fields_dev",
+    "colphys_zm_conv_tend_2_dev", "colphys_convect_diagnostics_dev", "colphys_derived_fields_dev", "colphys_dry_mass_fields_dev",
     "colphys_aero_tables_set",
     "colphys_modal_aero_sw_dev", "colphys_modal_aero_lw_dev",
     "colphys_modal_aero_sw_chunks", "colphys_modal_aero_lw_chunks",
@@ -215,18 +215,21 @@ class ColumnPhysics:
         return out
 
     # ---- zm_conv_tend on resident data (zm_conv_intr.F90:441-905) -------------------------------------
-    def alloc_zm_conv_tend_out(self, n, pver, pcols):
+    def alloc_zm_conv_tend_out(self, n, pver, pcols, hist=False):
+        """hist: also the ABI-4 history / argument outputs (abi.ZM_TEND_HIST), which otherwise stay in the engine's work arrays"""
         t = self.torch
-        shape = {0: (n,), 1: (n, pver), 2: (n, pver + 1), 3: ((n + pcols - 1) // pcols,)}
-        o = {k: self.empty(*shape[lv]) for k, lv in {**abi.ZM_TEND_OUT, **abi.ZM_TEND_DIAG, **abi.ZM_TEND_STATE1}.items()}
+        shape = {0: (n,), 1: (n, pver), 2: (n, pver + 1), 3: ((n + pcols - 1) // pcols,), 4: (2, n, pver)}
+        fields = {**abi.ZM_TEND_OUT, **abi.ZM_TEND_DIAG, **abi.ZM_TEND_STATE1, **(abi.ZM_TEND_HIST if hist else {})}
+        o = {k: self.empty(*shape[lv]) for k, lv in fields.items()}
         o.update({k: self.empty(*shape[lv], dtype=t.int32) for k, lv in abi.ZM_TEND_OUT_I.items()})
         o["status"] = self.empty(n, dtype=t.int32)
         return o
 
-    def zm_conv_tend(self, state: dict, ztodt, pcols=16, dycore=abi.DYCORE_FV, qmin=1.0e-12, out=None):
-        """state: device tensors named as abi.ZM_TEND_IN; returns ptend_all, the pbuf fields, diagnostics and state1."""
+    def zm_conv_tend(self, state: dict, ztodt, pcols=16, dycore=abi.DYCORE_FV, qmin=1.0e-12, out=None, hist=False):
+        """state: device tensors named as abi.ZM_TEND_IN; returns ptend_all, the pbuf fields, diagnostics and state1
+        (hist: and the history / argument outputs of abi.ZM_TEND_HIST)."""
         n, pver = state["t"].shape
-        o = self.alloc_zm_conv_tend_out(n, pver, pcols) if out is None else out
+        o = self.alloc_zm_conv_tend_out(n, pver, pcols, hist) if out is None else out
         io = abi.ZmConvTendIO()
         for k in abi.ZM_TEND_IN:
             setattr(io, k, _p(self._f64(state[k])))
@@ -288,6 +291,20 @@ class ColumnPhysics:
         io.qmin = abi.dptr(qm)
         self._check(self.lib.colphys_derived_fields_dev(C.c_int(n), C.c_int(pver), C.c_int(ncnst), C.c_int(dycore), C.c_int(nspecies),
                                                         C.c_double(gravit), C.byref(io), self._stream()))
+        return out
+
+    # ---- set_state_pdry + set_wet_to_dry + qneg3 (fv/dp_coupling.F90:630-651, physics_types.F90:1925-1984) -----------
+    def dry_mass_fields(self, pint, pdel, q, isdry, qmin):
+        """q: [ncnst][ncol][pver], converted / clipped in place; isdry, qmin: host sequences of ncnst; returns the dry-pressure fields"""
+        ncnst, n, pver = q.shape
+        shape = {0: (n,), 1: (n, pver), 2: (n, pver + 1)}
+        out = {k: self.empty(*shape[lv]) for k, lv in abi.DRY_MASS_OUT.items()}
+        io = abi.DryMassIO()
+        for k, v in dict(pint=pint, pdel=pdel, q=q, **out).items():
+            setattr(io, k, _p(self._f64(v)))
+        dry = np.ascontiguousarray(isdry, dtype=np.int32); qm = np.ascontiguousarray(qmin, dtype=np.float64)
+        io.isdry = abi.iptr(dry); io.qmin = abi.dptr(qm)
+        self._check(self.lib.colphys_dry_mass_fields_dev(C.c_int(n), C.c_int(pver), C.c_int(ncnst), C.byref(io), self._stream()))
         return out
 
     # ---- convect_diagnostics_calc (convect_diagnostics.F90:115-249) --------------------------------------

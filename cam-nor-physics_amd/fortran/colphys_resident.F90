@@ -44,6 +44,12 @@ module colphys_resident
      type(c_ptr) :: mu_out, md_out
      type(c_ptr) :: t1, q1, u1, v1, zi1, zm1
      type(c_ptr) :: status
+     ! ABI 4: zm_conv_tend's remaining intent(out) arguments and its outfld-only quantities (null: kept in work arrays)
+     type(c_ptr) :: cme = c_null_ptr, zdu = c_null_ptr, dif = c_null_ptr, eurt = c_null_ptr, pflx = c_null_ptr
+     type(c_ptr) :: zmdt_s = c_null_ptr, zmdq = c_null_ptr
+     type(c_ptr) :: evap_s = c_null_ptr, evap_s_snwprd = c_null_ptr, evap_s_snwevmlt = c_null_ptr
+     type(c_ptr) :: ntprprd = c_null_ptr, ntsnprd = c_null_ptr, seten = c_null_ptr
+     type(c_ptr) :: pguall = c_null_ptr, pgdall = c_null_ptr, icwu = c_null_ptr, icwd = c_null_ptr
   end type colphys_zm_conv_tend_io
 
   ! include/colphys.h: colphys_zm_conv_tend_2_io

@@ -74,9 +74,13 @@ contains
     allocate(a_piln(np,pverp), a_pint(np,pverp), a_pmid(np,pver), a_pdel(np,pver), a_rpdel(np,pver))
     a_piln = piln(:np,:pverp); a_pint = pint(:np,:pverp); a_pmid = pmid(:np,:pver); a_pdel = pdel(:np,:pver)
     a_rpdel = rpdel(:np,:pver); a_t = t(:np,:pver); a_rair = rair(:np,:pver); a_zvir = zvir(:np,:pver)
-    do idx = 1, nsp
-       a_q(:,:,idx) = q(:np,:pver,thermodynamic_active_species_idx(idx))
-    end do
+    if (kind == COLPHYS_DYCORE_SE) then
+       do idx = 1, nsp
+          a_q(:,:,idx) = q(:np,:pver,thermodynamic_active_species_idx(idx))
+       end do
+    else
+       a_q(:,:,1) = q(:np,:pver,1)             ! the reference reads q(i,k,1) whatever the active-species list holds (:107, :241)
+    end if
     ncol_c(1) = ncol
     rc = colphys_geopotential_t_chunks(1, np, pver, ncol_c, kind, nsp, nsp, c_loc(a_piln), c_null_ptr, c_loc(a_pint), &
                                        c_loc(a_pmid), c_loc(a_pdel), c_loc(a_rpdel), c_loc(a_t), c_loc(a_q), &
@@ -120,9 +124,13 @@ contains
     a_piln = piln(:np,:pverp); a_pint = pint(:np,:pverp); a_pmid = pmid(:np,:pver); a_pdel = pdel(:np,:pver)
     a_rpdel = rpdel(:np,:pver); a_dse = dse(:np,:pver); a_rair = rair(:np,:pver); a_cpair = cpair(:np,:pver)
     a_zvir = zvir(:np,:pver); a_phis = phis(:np)
-    do idx = 1, nsp
-       a_q(:,:,idx) = q(:np,:pver,thermodynamic_active_species_idx(idx))
-    end do
+    if (kind == COLPHYS_DYCORE_SE) then
+       do idx = 1, nsp
+          a_q(:,:,idx) = q(:np,:pver,thermodynamic_active_species_idx(idx))
+       end do
+    else
+       a_q(:,:,1) = q(:np,:pver,1)             ! the reference reads q(i,k,1) whatever the active-species list holds (:107, :241)
+    end if
     ncol_c(1) = ncol
     rc = colphys_geopotential_dse_chunks(1, np, pver, ncol_c, kind, nsp, nsp, c_loc(a_piln), c_null_ptr, c_loc(a_pint), &
                                          c_loc(a_pmid), c_loc(a_pdel), c_loc(a_rpdel), c_loc(a_dse), c_loc(a_q), c_loc(a_phis), &

@@ -346,6 +346,7 @@ contains
          'AODDUST      ', 'AODSS        ' /)
     ! outfld order of the reference: the seven summed visible-band fields (:1094-1118), then the climate-list set (:1130-1209)
     integer, parameter :: first_set(7)  = (/ 101, 102, 1, 2, 3, 4, 103 /)            ! 100 + level field, else column field
+    integer, parameter :: first_set_day(7) = (/ 101, 102, 1, 3, 2, 4, 103 /)         ! the day-only set swaps AODTOT and AODABS (:1112-1118)
     integer, parameter :: second_set(23) = (/ 5, 6, 104, 105, 7, 8, 9, 10, 15, 11, 12, 13, 14, 16, 17, 22, 18, 19, 20, 21, 23, 0, 0 /)
 
     real(c_double), allocatable, target :: pdeldry(:,:), specmmr(:,:,:,:), dgnumwet(:,:,:), qaerwat(:,:,:)
@@ -395,7 +396,7 @@ contains
       dlev(idxnite(i),:,1:3) = fillvalue
       dcol(idxnite(i),1:4)   = fillvalue
     end do
-    call put_set(first_set, 7, '')                                                  ! :1112-1118
+    call put_set(first_set_day, 7, '')                                              ! :1112-1118
 
     do i = 1, ncol                                                                  ! :1122-1128: aodvis is night-filled by now
       if (dcol(i,1) > 1.e-10_r8) then

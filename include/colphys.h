@@ -16,7 +16,9 @@
  *   colphys_momtran*                 momtran                  physics/zm_conv.F90:2315-2715
  *   colphys_convtran*                convtran                 physics/zm_conv.F90:1976-2311
  *   colphys_convect_diagnostics_dev  convect_diagnostics_calc physics/convect_diagnostics.F90:115-249
- *   colphys_derived_fields_dev       d_p_coupling, 'derived_fields' block   fv/dp_coupling.F90:550-625
+ *   colphys_derived_fields_dev       d_p_coupling, 'derived_fields' block   fv/dp_coupling.F90:550-629
+ *   colphys_dry_mass_fields_dev      ... its tail: set_state_pdry, set_wet_to_dry, qneg3   fv/dp_coupling.F90:630-651,
+ *                                    physics/physics_types.F90:1925-1984
  *   colphys_zm_conv_tend_2_dev       zm_conv_tend_2           physics/zm_conv_intr.F90:955-1028 (and the convtran1
  *                                    step of zm_conv_tend, :860-884) on resident data
  *   colphys_aero_tables_set          rad_cnst_get_mode_props / rad_cnst_get_aer_props data consumed at
@@ -75,7 +77,7 @@
 extern "C" {
 #endif
 
-#define COLPHYS_ABI_VERSION 3
+#define COLPHYS_ABI_VERSION 4
 
 #define COLPHYS_OK             0
 #define COLPHYS_ERR_ARG      (-1)
@@ -280,8 +282,8 @@ int colphys_zm_conv_tend_2_dev(int ncol, int pver, int pcols, int ncnst, double 
  *     geopotential_t(lnpint, lnpmid, pint, pmid, pdel, rpdel, t, q, rairv, gravit, zvirv) -> zi, zm        :617-621
  *     s = cpairv t + gravit zm + phis                                                                      :624-629
  * q is [ncnst][ncol][pver], in/out; qmin a HOST array of ncnst lower bounds (constituents' qmin).
- * Not included (host / upstream code): physics_cnst_limit, cam_thermo_dry_air_update, set_state_pdry / set_wet_to_dry,
- * qneg3, check_energy_timestep_init (:593-651).
+ * The block's tail -- set_state_pdry, set_wet_to_dry, qneg3 (:630-651) -- is colphys_dry_mass_fields_dev below.
+ * Not included (host / upstream code): physics_cnst_limit, cam_thermo_dry_air_update (WACCM-X only), check_energy_timestep_init.
  * ------------------------------------------------------------------------------------------------- */
 typedef struct colphys_derived_fields_io {
     const double *pint, *lnpint;                     /* [ncol][pver+1] */
@@ -297,6 +299,28 @@ typedef struct colphys_derived_fields_io {
 
 int colphys_derived_fields_dev(int ncol, int pver, int ncnst, int dycore_kind, int nspecies, double gravit,
                                const colphys_derived_fields_io *io, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * The dry-mass tail of d_p_coupling's derived fields  (fv/dp_coupling.F90:630-651) on resident data:
+ *     set_state_pdry  (physics_types.F90:1925-1964): pdeldry = pdel (1 - q(:,:,1)); pintdry(1) = pint(1),
+ *         pintdry(k+1) = pintdry(k) + pdeldry(k); pmiddry = (pintdry(k+1) + pintdry(k))/2; psdry = pint(1) + sum pdeldry;
+ *         rpdeldry = 1/pdeldry; lnpmiddry = log(pmiddry); lnpintdry = log(pintdry)
+ *     set_wet_to_dry  (:1968-1984): q(:,:,m) = q(:,:,m) pdel/pdeldry for every constituent of type 'dry'
+ *     qneg3 over 1..pcnst, then once more for cloud liquid and ice (:644-651; idempotent): q < qmin(m) -> qmin(m)
+ * q is [ncnst][ncol][pver], in/out, water vapour first; isdry, qmin are HOST arrays of ncnst.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct colphys_dry_mass_io {
+    const double *pint;                              /* [ncol][pver+1] */
+    const double *pdel;                              /* [ncol][pver]   */
+    double *q;                                       /* [ncnst][ncol][pver] in/out */
+    const int32_t *isdry;                            /* HOST [ncnst]: cnst_type(m) == 'dry' */
+    const double *qmin;                              /* HOST [ncnst]   */
+    double *pdeldry, *rpdeldry, *pmiddry, *lnpmiddry; /* [ncol][pver]   out */
+    double *pintdry, *lnpintdry;                     /* [ncol][pver+1] out */
+    double *psdry;                                   /* [ncol]         out */
+} colphys_dry_mass_io;
+
+int colphys_dry_mass_fields_dev(int ncol, int pver, int ncnst, const colphys_dry_mass_io *io, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * convect_diagnostics_calc  (convect_diagnostics.F90:115-249): merges the deep scheme's outputs with the shallow scheme's
@@ -488,6 +512,17 @@ typedef struct colphys_zm_conv_tend_io {
     /* state1 after the three updates (any may be NULL) */
     double *t1, *q1, *u1, *v1, *zi1, *zm1;
     int32_t *status;                                               /* [ncol] */
+    /* ABI 4 -- zm_conv_tend's own intent(out) arguments besides mcon (:420-427) and everything else it hands to outfld
+     * (:677-731, :781-792, :845-857).  Any may be NULL: the quantity then stays in the engine's work arrays.  The heating
+     * rates are J/kg/s as the kernels produce them; the history fields of the same name divided by cpair are the caller's
+     * (ZMDT = zmdt_s/cpair, EVAPTZM = evap_s/cpair, FZSNTZM, EVSNTZM, ZMMTT = seten/cpair), exactly as in the reference. */
+    double *cme, *zdu, *dif, *eurt;                                /* [ncol][pver]: cme, zdu; DIFZM; eurt (EURT = eurt(:,pver)) */
+    double *pflx;                                                  /* [ncol][pver+1] */
+    double *zmdt_s, *zmdq;                                         /* zm_convr's ptend_loc%s, %q(:,:,1): ZMDT x cpair, ZMDQ */
+    double *evap_s, *evap_s_snwprd, *evap_s_snwevmlt;              /* zm_conv_evap: ZMEIHEAT, FZSNTZM x cpair, EVSNTZM x cpair */
+    double *ntprprd, *ntsnprd;                                     /* ZMNTPRPD, ZMNTSNPD */
+    double *seten;                                                 /* momtran's dissipative heating: ZMMTT x cpair */
+    double *pguall, *pgdall, *icwu, *icwd;                         /* [2][ncol][pver] (u, v): ZM{U,V}PGU, ZM{U,V}PGD, ZMIC{U,V}U, ZMIC{U,V}D */
 } colphys_zm_conv_tend_io;
 
 /* qmin: lower bound physics_update's qneg3 applies to water vapour (constituents' qmin(1), 1e-12 in CAM) */

@@ -187,6 +187,13 @@ class RefIntrOracle:
             *[_d(_c(x if x is not None else z)) for x in (s, q, u, v)], _d(o["zi"]), _d(o["zm"]), _d(o["s"]))
         return o
 
+    # -- oslo_aero_microp_register / _init / _run (physics/oslo_aero_microp.F90:10-25) -------------------------------
+    def oslo_aero_microp(self):
+        """-> dict(fields_flagged, components_allocated, use_oslo_aero, nbmodes) after register, init and one run"""
+        w = np.zeros(4, np.int32)
+        self.lib.ref_oslo_aero_microp(_i(w))
+        return dict(fields_flagged=int(w[0]), components_allocated=int(w[1]), use_oslo_aero=bool(w[2]), nbmodes=int(w[3]))
+
     # -- set_state_pdry + set_wet_to_dry + qneg3, the tail of d_p_coupling's derived fields (fv/dp_coupling.F90:630-657) ----
     def dp_coupling_dry_tail(self, pint, pdel, q):
         n, pver = pdel.shape

@@ -493,4 +493,29 @@ contains
     end do
   end subroutine ref_dp_coupling_dry_tail
 
+  ! ---- oslo_aero_microp (physics/oslo_aero_microp.F90:10-25; BASELINE config 4) -----------------------------------
+  ! register / init / run as tphysac would call them (physpkg.F90:1801-1804): what(1) = fields flagged in ptend_all after
+  ! the run, what(2) = components of ptend_all allocated, what(3) = use_oslo_aero, what(4) = nbmodes
+  subroutine ref_oslo_aero_microp(what) bind(C, name='ref_oslo_aero_microp')
+    use oslo_aero_microp, only: oslo_aero_microp_register, oslo_aero_microp_init, oslo_aero_microp_run
+    use oslo_aero_share,  only: use_oslo_aero, nbmodes
+    integer(c_int), intent(out) :: what(4)
+    type(physics_state) :: state
+    type(physics_ptend) :: ptend_all
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    pbuf => pbuf2d(:, 1)
+    ncols_of_chunk = pcols
+    call physics_state_alloc(state, 1, pcols)
+    state%ncol = pcols
+    call oslo_aero_microp_register()
+    call oslo_aero_microp_init()
+    call oslo_aero_microp_run(state, ptend_all, 1800._r8, pbuf)
+    what(1) = count(ptend_all%lq) + merge(1, 0, ptend_all%ls) + merge(1, 0, ptend_all%lu) + merge(1, 0, ptend_all%lv)
+    what(2) = merge(1, 0, allocated(ptend_all%s)) + merge(1, 0, allocated(ptend_all%q)) + merge(1, 0, allocated(ptend_all%u)) &
+            + merge(1, 0, allocated(ptend_all%v))
+    what(3) = merge(1, 0, use_oslo_aero)
+    what(4) = nbmodes
+    call physics_state_dealloc(state)
+  end subroutine ref_oslo_aero_microp
+
 end module ref_wrap_intr

@@ -331,7 +331,9 @@ contains
     end do
   end subroutine ref_convtran
 
+#ifndef COLPHYS_SHIM_BUILD
   ! ---- L0 seams (oracle/stubs/l0_arithmetic.F90), exported so the C restatement can be pinned to them ----
+  ! (oracle builds only: the shim libraries compile this file with -DCOLPHYS_SHIM_BUILD and link nothing of the oracle's arithmetic)
   subroutine ref_qsat_water(n, t, p, es, qs) bind(C, name='ref_qsat_water')
     use wv_saturation, only: qsat_water
     integer(c_int), value :: n
@@ -350,5 +352,6 @@ contains
     real(c_double), intent(out) :: es(n), qs(n)
     call qsat(t, p, es, qs, n)
   end subroutine ref_qsat_table
+#endif
 
 end module ref_wrap_zm

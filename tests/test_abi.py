@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/colphys.h but not exported by {LIB}"
     assert set(EXPORTED_SYMBOLS) == set(syms)
-    assert lib.colphys_abi_version() == 3
+    assert lib.colphys_abi_version() == 4
 
 
 def test_gfx950_code_object_is_embedded():
@@ -46,16 +46,18 @@ def test_struct_layouts_match_the_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "colphys.h"\n'
-        'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(colphys_zm_params), offsetof(colphys_zm_params, limcnv),'
+        'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(colphys_zm_params), offsetof(colphys_zm_params, limcnv),'
         ' sizeof(colphys_zm_convr_io), offsetof(colphys_zm_convr_io, jt), sizeof(colphys_zm_conv_evap_io), sizeof(colphys_momtran_io),'
         ' sizeof(colphys_aero_tables), offsetof(colphys_aero_tables, nspec), sizeof(colphys_modal_aero_io),'
-        ' sizeof(colphys_convtran_io), sizeof(colphys_zm_conv_tend_2_io), sizeof(colphys_zm_conv_tend_io), sizeof(colphys_convect_diag_io), sizeof(colphys_derived_fields_io));return 0;}\n')
+        ' sizeof(colphys_convtran_io), sizeof(colphys_zm_conv_tend_2_io), sizeof(colphys_zm_conv_tend_io), sizeof(colphys_convect_diag_io), sizeof(colphys_derived_fields_io),'
+        ' sizeof(colphys_dry_mass_io), offsetof(colphys_zm_conv_tend_io, cme));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(abi.ZmParams), abi.ZmParams.limcnv.offset, C.sizeof(abi.ZmConvrIO), abi.ZmConvrIO.jt.offset,
             C.sizeof(abi.ZmConvEvapIO), C.sizeof(abi.MomtranIO), C.sizeof(abi.AeroTables), abi.AeroTables.nspec.offset,
-            C.sizeof(abi.ModalAeroIO), C.sizeof(abi.ConvtranIO), C.sizeof(abi.ZmConvTend2IO), C.sizeof(abi.ZmConvTendIO), C.sizeof(abi.ConvectDiagIO), C.sizeof(abi.DerivedFieldsIO)]
+            C.sizeof(abi.ModalAeroIO), C.sizeof(abi.ConvtranIO), C.sizeof(abi.ZmConvTend2IO), C.sizeof(abi.ZmConvTendIO), C.sizeof(abi.ConvectDiagIO), C.sizeof(abi.DerivedFieldsIO),
+            C.sizeof(abi.DryMassIO), abi.ZmConvTendIO.cme.offset]
     assert got == want
 
 

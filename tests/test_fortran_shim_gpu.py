@@ -156,3 +156,51 @@ def test_shim_halts_where_the_reference_halts(case, extra, halts, message):
         assert r.returncode != 0 and "RETURNED" not in r.stdout and "ENDRUN:" in out, out[-2000:]
     else:
         assert r.returncode == 0 and "RETURNED" in r.stdout and "ENDRUN:" not in out, out[-2000:]
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's OPERATOR files on the HIP engine, not a line changed
+# ---------------------------------------------------------------------------------------------------
+_shimintr = {}
+
+
+def shimintr(pver, tab):
+    """libcolphys_shimintr_*: /root/reference/physics/{physics_types,zm_conv_intr,convect_diagnostics}.F90 compiled unmodified
+    against the shim's `module zm_conv` / `module geopotential` (cam-nor-physics_amd/fortran/Makefile, target intr)"""
+    from ref_intr_oracle import RefIntrOracle
+    path = os.path.join(ROOT, "cam-nor-physics_amd", "_build", f"libcolphys_shimintr_p16_l{pver}.so")
+    assert os.path.exists(path), "build it where /root/reference exists: make -C cam-nor-physics_amd/fortran intr"
+    if pver not in _shimintr:           # zm_conv_init allocates module state of zm_conv_intr once per process
+        pe = synth.PTOP + synth.sigma_edges(pver) * (1.0e5 - synth.PTOP)
+        _shimintr[pver] = RefIntrOracle(synth.ZM_NAMELIST, pe, 16, pver, lib_path=path, **tab)
+    return _shimintr[pver]
+
+
+@pytest.mark.parametrize("name", cases.INTR_GOLDEN)
+def test_reference_zm_conv_tend_unmodified_on_hip_engine_matches_reference_golden(name):
+    """zm_conv_intr.F90's zm_conv_tend and zm_conv_tend_2 -- the reference's own source: pbuf lookups, physics_state_copy,
+    zm_convr, outfld, physics_ptend_sum, physics_update (whose geopotential_t is the shim's too), zm_conv_evap, momtran, convtran
+    -- linked against the shim instead of zm_conv.F90 / geopotential.F90, against the fixtures the all-reference build wrote:
+    ptend_all, every pbuf field, every outfld value, zm_conv_tend_2's tracer tendencies.  1e-10 relative."""
+    g = cases.load_golden(name)
+    pver = int(g["pver"])
+    tab = {k[4:]: g[k] for k in ("tab_isdry", "tab_lq1", "tab_lq2", "tab_qmin")}
+    f = shimintr(pver, tab)
+    st = cases.intr_state_from_golden(g)
+    o = f.zm_conv_tend(st, synth.ZTODT, q=g["in_q6"], fracis=g["in_fracis6"])
+    r = {k: v for k, v in o.items() if k not in ("q_in", "fracis_in", "ptend_lq")}
+    r["ptend_q"] = o["ptend_q"][:6]
+    assert np.array_equal(o["ptend_lq"], g["tend_ptend_lq"])
+    cases.assert_tend_matches_golden(r, g)
+    assert set(r["hist"]) == {k[5:] for k in g if k.startswith("hist_")}
+    pq, lq = f.zm_conv_tend_2(g["in_q6"], g["in_pdeldry"], g["in_fracis6"], *[o[k] for k in ("mu", "md", "du", "eu", "ed", "dp", "dsubcld",
+                                                                                                   "jt", "maxg", "ideep")], synth.ZTODT)
+    assert np.array_equal(lq, g["tend2_lq"])
+    for m in range(6):
+        assert_close(f"zm_conv_tend_2.ptend_q[{m}]", pq[m], g["tend2_ptend_q"][m])
+    # physics_update of the reference's physics_types.F90 with the shim's geopotential_t inside it (physics_types.F90:436)
+    pu = f.physics_update(st, synth.ZTODT, s=g["pu_tend_s"], q=g["pu_tend_q"], u=g["pu_tend_u"], v=g["pu_tend_v"])
+    for k in ("t", "q", "u", "v", "zi", "zm", "s"):
+        assert_close("physics_update." + k, pu[k], g["pu_" + k])
+    # BASELINE config 4's oslo_aero_microp: the engine's drop-in module behind the same driver as the reference's empty one
+    assert f.oslo_aero_microp() == dict(fields_flagged=0, components_allocated=0, use_oslo_aero=False, nbmodes=0)

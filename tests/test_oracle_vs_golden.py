@@ -265,3 +265,25 @@ def test_physics_update_and_dry_tail_restatements_vs_reference_operator_golden(n
         ref = g["dry_" + k]
         assert_close("dry tail " + k, v, ref, rtol=1e-15)
     assert (g["dry_q"][4] != g["dry_in_q6"][4]).any() and (g["dry_q"] >= 0).all() and (g["dry_in_q6"] < 0).any()
+
+
+def test_oslo_aero_microp_hook_of_the_reference_does_nothing():
+    """BASELINE config 4 names oslo_aero_microp: in the reference it is three empty procedures behind use_oslo_aero = .false.
+    (physics/oslo_aero_microp.F90:10-25, oslo_aero_share.F90:8-9).  The same driver (oracle/ref_wrap_intr.F90) calls register,
+    init and run of the reference's module and of the engine's drop-in module (fortran/oslo_aero_microp_hip.F90, linked into the
+    shim twin; tests/test_fortran_shim_gpu.py runs it): same signature or the driver would not compile, no tendency flagged,
+    nothing allocated, the same two switches."""
+    import os
+    import subprocess
+    import sys
+    from ref_intr_oracle import have_refintr
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not have_refintr(16, 32):
+        pytest.skip("built only where /root/reference exists")
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "from ref_intr_oracle import RefIntrOracle\nfrom cam_nor_physics_amd import synth\n"
+            "pe = synth.PTOP + synth.sigma_edges(32) * (1.0e5 - synth.PTOP)\n"
+            "print(RefIntrOracle(synth.ZM_NAMELIST, pe, 16, 32, lib_path=%s).oslo_aero_microp())\n")
+    want = "{'fields_flagged': 0, 'components_allocated': 0, 'use_oslo_aero': False, 'nbmodes': 0}"
+    ref = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "oracle"), "None")], capture_output=True, text=True, timeout=300)
+    assert ref.returncode == 0 and ref.stdout.strip().endswith(want), ref.stdout + ref.stderr[-500:]
