@@ -19,6 +19,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
+    # .hip, .h and .inc alike
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "colphys.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

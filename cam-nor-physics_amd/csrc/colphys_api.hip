@@ -29,6 +29,7 @@ double *g_estbl = nullptr;          // device, [PLENEST+1], 1-based
 AeroDev g_A;
 bool g_aero_set = false;
 std::vector<void *> g_aero_bufs;
+std::vector<int> g_hf_nspec;        // host copy of the tables' species counts per mode (the host face names its fields by them)
 
 int fail(int code, const std::string &msg)
 {
@@ -331,7 +332,7 @@ int colphys_geopotential_dse_dev(int ncol, int pver, int dycore_kind, int nq, in
 }
 
 static int zm_convr_impl(int ncol, int pver, int pcols, double delt, const colphys_zm_convr_io *io, void *stream,
-                         const ZmTendDiag *diag)
+                         const ZmTendDiag *diag, Arena *ws_arena = &g_ws_arena)
 {
     int rc;
     if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
@@ -349,8 +350,8 @@ static int zm_convr_impl(int ncol, int pver, int pcols, double delt, const colph
     ZmWorkspace ws;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        if (g_ws_arena.reserve(zm_ws_bytes(ncol, pver))) return fail(COLPHYS_ERR_HIP, "workspace allocation failed");
-        ws = zm_ws_carve(g_ws_arena.p, ncol, pver);
+        if (ws_arena->reserve(zm_ws_bytes(ncol, pver))) return fail(COLPHYS_ERR_HIP, "workspace allocation failed");
+        ws = zm_ws_carve(ws_arena->p, ncol, pver);
     }
     hipEvent_t ev[8];
     if (g_prof) for (auto &e : ev) e = ev_get();
@@ -527,8 +528,10 @@ int colphys_physics_update_dev(int ncol, int pver, double dt, double cpair, doub
 }
 
 // ---- zm_conv_tend on resident data (zm_conv_intr.F90:441-905) ---------------------------------------------------
-int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dycore_kind, double qmin,
-                             const colphys_zm_conv_tend_io *io, void *stream)
+// ws_arena / tend_arena: the work arrays of this call.  The public entry uses the library's own pair (calls ordered by the
+// caller); the host face runs several column slices on several streams at once and gives each stream a pair of its own.
+static int zm_conv_tend_impl(int ncol, int pver, int pcols, double ztodt, int dycore_kind, double qmin,
+                             const colphys_zm_conv_tend_io *io, void *stream, Arena *ws_arena, Arena *tend_arena)
 {
     int rc;
     if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
@@ -550,8 +553,8 @@ int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dy
     // work arrays: ptend_loc of the three stages, what zm_conv_tend only hands to outfld, and state1
     std::unique_lock<std::mutex> lk(g_mu);
     const size_t bytes = 8 * (30 * nM + 3 * nI + 8 * (size_t)ncol) + 64 * 256;
-    if (g_tend_arena.reserve(bytes)) return fail(COLPHYS_ERR_HIP, "work-array allocation failed");
-    Carver w(g_tend_arena.p);
+    if (tend_arena->reserve(bytes)) return fail(COLPHYS_ERR_HIP, "work-array allocation failed");
+    Carver w(tend_arena->p);
     lk.unlock();
     // (a work array the caller asked for by name -- ABI 4 history outputs -- lives in the caller's buffer instead)
     auto mid = [&](double *user, size_t n) { return user ? user : w.take<double>(n); };
@@ -579,7 +582,7 @@ int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dy
     ZmTendDiag dg{};
     dg.enabled = 1; dg.gravit = g_P.gravit; dg.mconzm = io->mconzm; dg.ps = io->ps; dg.pmid = io->pmid;
     dg.freqzm = io->freqzm; dg.pcont = io->pcont; dg.pconb = io->pconb; dg.mu_out = io->mu_out; dg.md_out = io->md_out;
-    if ((rc = zm_convr_impl(ncol, pver, pcols, 0.5 * ztodt, &c, stream, &dg))) return rc;
+    if ((rc = zm_convr_impl(ncol, pver, pcols, 0.5 * ztodt, &c, stream, &dg, ws_arena))) return rc;
 
     auto update = [&](const double *ti, const double *s, const double *qi, const double *qt, const double *ui, const double *ut,
                       const double *vi, const double *vt, int first) -> int {
@@ -620,6 +623,12 @@ int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dy
     // ptend_all%u, %v start here (nothing wrote them before); %s accumulates
     if ((rc = update(t1, seten, nullptr, nullptr, io->u, wtend, io->v, wtend + nM, 4 | 8))) return fail(rc, "physics_update launch failed");
     return geopotential();
+}
+
+int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dycore_kind, double qmin,
+                             const colphys_zm_conv_tend_io *io, void *stream)
+{
+    return zm_conv_tend_impl(ncol, pver, pcols, ztodt, dycore_kind, qmin, io, stream, &g_ws_arena, &g_tend_arena);
 }
 
 int colphys_math_probe_dev(int kind, int64_t n, const double *x, double *y, void *stream)
@@ -781,6 +790,7 @@ int colphys_aero_tables_set(const colphys_aero_tables *tb)
         for (size_t m = 0; m < nm; ++m) A.nspec_total += tb->nspec[m];
     }
     if (bad) return fail(COLPHYS_ERR_HIP, "uploading packed aerosol table slices failed");
+    g_hf_nspec.assign(tb->nspec, tb->nspec + tb->nmodes);
     g_aero_set = true;
     return COLPHYS_OK;
 }
@@ -1369,3 +1379,5 @@ int colphys_modal_aero_sw_chunks(int nchunks, int pcols, int pver, const int32_t
 int colphys_modal_aero_lw_chunks(int nchunks, int pcols, int pver, const int32_t *ncol, const colphys_modal_aero_io *io) { return aero_chunks(false, nchunks, pcols, pver, ncol, io); }
 
 }  // extern "C"
+
+#include "colphys_hostface.inc"

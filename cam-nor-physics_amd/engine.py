@@ -71,6 +71,8 @@ EXPORTED_SYMBOLS = [
     "colphys_modal_aero_sw_chunks", "colphys_modal_aero_lw_chunks",
     "colphys_modal_aero_sw_diag_dev", "colphys_modal_aero_sw_diag_chunks", "colphys_aero_grid_probe_dev", "colphys_aero_kernel_select",
     "colphys_profile_enable", "colphys_profile_reset", "colphys_profile_get", "colphys_math_probe_dev",
+    "colphys_hostface_create", "colphys_hostface_destroy", "colphys_hostface_geometry", "colphys_hostface_field",
+    "colphys_hostface_in_base", "colphys_hostface_out_base", "colphys_hostface_run", "colphys_hostface_last_times",
 ]
 
 

@@ -530,6 +530,65 @@ int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dy
                              const colphys_zm_conv_tend_io *io, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * The whole-rank HOST FACE: physics_state / pbuf / ptend arrays of every chunk of a rank, in the reference's own
+ * per-chunk layout -- Fortran (pcols, nlev), column index fastest, exactly what state(c)%t, ptend(c)%s or a pbuf field
+ * is (physics_types.F90:62-121, 137-173) -- in PINNED host memory that the caller fills and reads in place.
+ *
+ * This is what replaces the chunk loop of phys_run1 (physpkg.F90:1147-1161) for the path: the loop body shrinks to
+ * copying state(c) into the chunk's record (thread-safe for distinct chunks: colphys_hostface_base + chunk * record
+ * size + field offset), ONE colphys_hostface_run for the rank, and a second loop copying the chunk's results out.
+ * Nothing is transposed on the host: a record goes to the device as it is, a HIP kernel re-lays it out to the engine's
+ * column-contiguous buffers at HBM speed, the kernels run, a second kernel re-lays the results out into output
+ * records, which come back as they are.  The rank is cut into `nslices` chunk ranges that are pipelined over four
+ * streams by role (upload, two for kernels, download), so that the upload of one slice, the kernels of another and the
+ * download of a third overlap (PCIe is full duplex): the wall time of a run tends to the larger of the two transfer times.
+ *
+ * Padding columns (i > ncol(chunk)) hold +inf in CAM: the device shadows them with the chunk's first column and
+ * drops them from the gathered sets again; their output slots are written but meaningless.
+ *
+ * Field names: inputs  t q u v pmid pdel rpdel lnpmid zm cld (pcols,pver); pint lnpint zi (pcols,pver+1); phis ps pblh tpert
+ *                      landfrac (pcols); with COLPHYS_HF_AERO: pdeldry, dgnumwet_<m>, qaerwat_<m>, specmmr_<m>_<l> (pcols,pver),
+ *                      m = 1..nmodes, l = 1..nspec(m); with COLPHYS_HF_SWDIAG: troplevchem (pcols) int32
+ *              outputs ptend_s ptend_q ptend_u ptend_v ql rprd evapcdp dlf mu md du eu ed dp (pcols,pver); mconzm flxprec flxsnow
+ *                      (pcols,pver+1); prec snow rliq rice jctop jcbot cape dsubcld freqzm pcont pconb (pcols); jt maxg ideep
+ *                      status (pcols) int32; lengath (1) int32; with COLPHYS_HF_HIST the ABI-4 history outputs of
+ *                      colphys_zm_conv_tend_io under their names there (pguall ... icwd as <name>_u, <name>_v); with
+ *                      COLPHYS_HF_AERO: sw_tauxar sw_wa sw_ga sw_fa (pcols, 0:pver, nswbands), lw_tauxar (pcols,pver,nlwbands),
+ *                      sw_status lw_status (pcols) int32; with COLPHYS_HF_SWDIAG: swd_lev (pcols,pver,COLPHYS_SWD_NLEV),
+ *                      swd_col (pcols, COLPHYS_SWD_NCOL + 3 nmodes)
+ * mu ... ideep keep the reference's per-chunk gathered layout (slot j of the chunk in row j).
+ * ------------------------------------------------------------------------------------------------- */
+#define COLPHYS_HF_ZM     1   /* zm_conv_tend (always on) */
+#define COLPHYS_HF_AERO   2   /* + modal_aero_sw, modal_aero_lw (colphys_aero_tables_set first) */
+#define COLPHYS_HF_SWDIAG 4   /* + modal_aero_sw's history diagnostics (needs COLPHYS_HF_AERO) */
+#define COLPHYS_HF_HIST   8   /* + zm_conv_tend's history / argument outputs (ABI 4) */
+
+typedef struct colphys_hostface colphys_hostface;
+
+/* ncol[nchunks]: active columns per chunk (1..pcols).  nslices >= 1 (0: chosen by the library). */
+int colphys_hostface_create(int nchunks, int pcols, int pver, const int32_t *ncol, int what, int nslices, colphys_hostface **hf);
+int colphys_hostface_destroy(colphys_hostface *hf);
+/* record geometry: bytes per chunk of the input / output records, number of fields */
+int colphys_hostface_geometry(const colphys_hostface *hf, int64_t *in_record_bytes, int64_t *out_record_bytes, int32_t *nfields);
+/* field i (0-based): name (<= 31 chars + NUL into name[32]), nlev (second dimension of the (pcols, nlev) array), is_int
+ * (int32 instead of fp64), is_out, byte offset inside its record */
+int colphys_hostface_field(const colphys_hostface *hf, int i, char *name, int32_t *nlev, int32_t *is_int, int32_t *is_out, int64_t *offset);
+/* pinned base addresses: chunk c's input record starts at in_base + c * in_record_bytes */
+void *colphys_hostface_in_base(colphys_hostface *hf);
+void *colphys_hostface_out_base(colphys_hostface *hf);
+/* H2D + device re-layout + zm_conv_tend (+ optics) + device re-layout + D2H for the whole rank; returns when the output
+ * records are complete.  dycore_kind / qmin as colphys_zm_conv_tend_dev. */
+int colphys_hostface_run(colphys_hostface *hf, double ztodt, int dycore_kind, double qmin);
+/* of the last run: wall time of the call; CPU time the calling thread spent in it; summed device time of the uploads,
+ * the two re-layout kernels, the physics kernels and the downloads (they overlap across slices); bytes moved each way */
+typedef struct colphys_hostface_times {
+    double wall_ms, host_cpu_ms, h2d_ms, relayout_ms, physics_ms, d2h_ms;
+    int64_t h2d_bytes, d2h_bytes;
+    int32_t nslices, nstreams;
+} colphys_hostface_times;
+int colphys_hostface_last_times(const colphys_hostface *hf, colphys_hostface_times *t);
+
+/* ---------------------------------------------------------------------------------------------------
  * Measurement helper: average device time (ms) of each kernel family since the last reset, measured
  * with HIP events on the launch stream when profiling is switched on (bench.py's roofline leg).
  * ------------------------------------------------------------------------------------------------- */

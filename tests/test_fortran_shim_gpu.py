@@ -204,3 +204,93 @@ def test_reference_zm_conv_tend_unmodified_on_hip_engine_matches_reference_golde
         assert_close("physics_update." + k, pu[k], g["pu_" + k])
     # BASELINE config 4's oslo_aero_microp: the engine's drop-in module behind the same driver as the reference's empty one
     assert f.oslo_aero_microp() == dict(fields_flagged=0, components_allocated=0, use_oslo_aero=False, nbmodes=0)
+
+
+@pytest.mark.parametrize("name", cases.INTR_GOLDEN)
+def test_fortran_physics_state_face_whole_rank_dispatch_matches_reference_operator_golden(name):
+    """The restructured chunk loop (fortran/colphys_hostface_mod.F90 driven by tests/fortran/hostface_driver.F90): one
+    physics_state per chunk, built by the reference's own physics_state_alloc (+inf padding), pushed chunk by chunk, ONE
+    dispatch for all of them, pulled into physics_ptend / zm_conv_tend's arguments / pbuf arrays -- against what the
+    reference's zm_conv_tend wrote for the same columns (tests/golden intr_*): ptend_all, the surface and pbuf fields, the
+    gathered sets.  The fixture has a chunk with no convecting column, chunks with several, and a ragged last chunk."""
+    import ctypes as C
+    g = cases.load_golden(name)
+    pver, n = int(g["pver"]), int(g["ncol"])
+    tab = {k[4:]: g[k] for k in ("tab_isdry", "tab_lq1", "tab_lq2", "tab_qmin")}
+    f = shimintr(pver, tab)                              # zm_conv_init -> the shim's zm_convi -> colphys_init
+    lib = f.lib
+    st = cases.intr_state_from_golden(g)
+    D = C.POINTER(C.c_double)
+    I = C.POINTER(C.c_int)
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    nch = (n + 15) // 16
+    o = {k: np.zeros((n, pver)) for k in ("ptend_s", "ptend_u", "ptend_v", "ptend_q", "ql", "rprd", "evapcdp", "dlf")}
+    o.update({k: np.zeros((nch * 16, pver)) for k in ("mu", "md", "du", "eu", "ed", "dp")})
+    o.update({k: np.zeros((n, pver + 1)) for k in ("mcon", "mconzm", "flxprec", "flxsnow")})
+    o.update({k: np.zeros(n) for k in ("rliq", "rice", "jctop", "jcbot", "prec", "snow", "cape", "freqzm", "pcont", "pconb")})
+    o["dsubcld"] = np.zeros(nch * 16)
+    o.update({k: np.zeros(nch * 16, np.int32) for k in ("jt", "maxg", "ideep")})
+    o["lengath"] = np.zeros(nch, np.int32)
+    times = np.zeros(2)
+    ins = [c(st[k]) for k in ("t", "u", "v", "q", "pmid", "pdel", "rpdel", "lnpmid", "zm", "pint", "lnpint", "zi", "phis")] + \
+          [c(st["pint"][:, -1])] + [c(st[k]) for k in ("pblh", "tpert", "landfrac", "cld")]
+    dp_ = lambda a: a.ctypes.data_as(D)
+    lib.hfd_zm_conv_tend(C.c_int(n), C.c_double(synth.ZTODT), *[dp_(a) for a in ins],
+                         *[dp_(o[k]) for k in ("ptend_s", "ptend_u", "ptend_v", "ptend_q", "mcon", "rliq", "rice", "jctop", "jcbot", "prec", "snow",
+                                               "ql", "rprd", "evapcdp", "dlf", "mconzm", "flxprec", "flxsnow", "mu", "md", "du", "eu", "ed", "dp",
+                                               "dsubcld")],
+                         *[o[k].ctypes.data_as(I) for k in ("jt", "maxg", "ideep", "lengath")],
+                         *[dp_(o[k]) for k in ("cape", "freqzm", "pcont", "pconb")], dp_(times))
+    r = {k: (v[:n] if k in ("mu", "md", "du", "eu", "ed", "dp", "dsubcld", "jt", "maxg", "ideep") else v) for k, v in o.items()}
+    r["ptend_q"] = o["ptend_q"][None]                   # water vapour; cloud liquid / ice are convtran1's (zm_conv_tend_2_dev)
+    r["hist"] = dict(CAPE=o["cape"], FREQZM=o["freqzm"], PCONVT=o["pcont"], PCONVB=o["pconb"], CMFMC_DP=o["mconzm"])
+    cases.assert_tend_matches_golden(r, g)
+    assert times[0] > 0 and times[1] < times[0]         # the dispatching thread mostly sleeps
+
+
+_HF_HALT = r"""
+import ctypes as C, os, sys
+import numpy as np
+root = sys.argv[1]
+for p in (root, os.path.join(root, "tests"), os.path.join(root, "oracle")):
+    sys.path.insert(0, p)
+import torch                                   # first: the process's HIP runtime is the one torch brings
+import cases
+from cam_nor_physics_amd import synth
+from ref_intr_oracle import RefIntrOracle
+pver, n = 32, 16 * 6 - 3
+pe = synth.PTOP + synth.sigma_edges(pver) * (1.0e5 - synth.PTOP)
+f = RefIntrOracle(synth.ZM_NAMELIST, pe, 16, pver, lib_path=os.path.join(root, "cam-nor-physics_amd", "_build", "libcolphys_shimintr_p16_l32.so"))
+st = synth.make_state(n, pver, 5)
+if sys.argv[2] == "nan":
+    st["t"] = st["t"].copy(); st["t"][37, :] = np.nan
+D, I = C.POINTER(C.c_double), C.POINTER(C.c_int)
+c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+nch = (n + 15) // 16
+mid, itf, col = (lambda: np.zeros((nch * 16, pver))), (lambda: np.zeros((n, pver + 1))), (lambda: np.zeros(nch * 16))
+ins = [c(st[k]) for k in ("t", "u", "v", "q", "pmid", "pdel", "rpdel", "lnpmid", "zm", "pint", "lnpint", "zi", "phis")] + [c(st["pint"][:, -1])] + \
+      [c(st[k]) for k in ("pblh", "tpert", "landfrac", "cld")]
+outs = [mid(), mid(), mid(), mid(), itf(), col(), col(), col(), col(), col(), col(), mid(), mid(), mid(), mid(), itf(), itf(), itf(),
+        mid(), mid(), mid(), mid(), mid(), mid(), col()]
+ints = [np.zeros(nch * 16, np.int32) for _ in range(4)]
+tail = [col(), col(), col(), col(), np.zeros(2)]
+f.lib.hfd_zm_conv_tend(C.c_int(n), C.c_double(synth.ZTODT), *[a.ctypes.data_as(D) for a in ins], *[a.ctypes.data_as(D) for a in outs],
+                       *[a.ctypes.data_as(I) for a in ints], *[a.ctypes.data_as(D) for a in tail])
+print("RETURNED deep", int(ints[3][:nch].sum()))
+"""
+
+
+@pytest.mark.parametrize("case,halts", [("clean", False), ("nan", True)])
+def test_fortran_whole_rank_dispatch_halts_where_the_reference_halts(case, halts):
+    """colphys_rank_run_zm_conv_tend reads the status words of the whole rank: a sounding that is not a number ends the run
+    with the reference's ienthalpy message (zm_conv.F90:5565; endrun here is the stand-in that stops the process, hence the
+    child process); clean soundings return."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _HF_HALT, ROOT, case], capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    if halts:
+        assert r.returncode != 0 and "RETURNED" not in r.stdout, out[-2000:]
+        assert "ENDRUN:" in out and "**** ZM_CONV IENTHALPY: Tmix did not converge ****" in out, out[-2000:]
+    else:
+        assert r.returncode == 0 and "RETURNED deep" in r.stdout and "ENDRUN:" not in out, out[-2000:]
