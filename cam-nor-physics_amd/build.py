@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(BUILD, "libcolphys_hip.so")
-SOURCES = ["colphys_api.hip", "k_zm_convr.hip", "k_scans.hip", "k_momtran.hip", "k_modal_aero.hip"]
+SOURCES = ["colphys_api.hip", "k_zm_convr.hip", "k_scans.hip", "k_modal_aero.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the parity path keeps the reference's operation order (no FMA contraction)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",

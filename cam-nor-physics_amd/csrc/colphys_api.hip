@@ -552,7 +552,7 @@ static int zm_conv_tend_impl(int ncol, int pver, int pcols, double ztodt, int dy
 
     // work arrays: ptend_loc of the three stages, what zm_conv_tend only hands to outfld, and state1
     std::unique_lock<std::mutex> lk(g_mu);
-    const size_t bytes = 8 * (30 * nM + 3 * nI + 8 * (size_t)ncol) + 64 * 256;
+    const size_t bytes = 8 * (33 * nM + 4 * nI + 8 * (size_t)ncol) + 64 * 256;
     if (tend_arena->reserve(bytes)) return fail(COLPHYS_ERR_HIP, "work-array allocation failed");
     Carver w(tend_arena->p);
     lk.unlock();
@@ -600,22 +600,42 @@ static int zm_conv_tend_impl(int ncol, int pver, int pcols, double ztodt, int dy
 
     // ---- ptend_all = ptend_loc; state1 = state + ptend_loc dt (:737-739) -----------------------------------
     if ((rc = update(io->t, heat, io->q, qtnd, nullptr, nullptr, nullptr, nullptr, 1 | 2))) return fail(rc, "physics_update launch failed");
-    if ((rc = geopotential())) return rc;
 
-    // ---- zm_conv_evap on state1 (:764-771); evapcdp = its dq/dt (:773) ----------------------------------------
     colphys_zm_conv_evap_io e{};
     e.t = t1; e.pmid = io->pmid; e.pdel = io->pdel; e.q = q1; e.prdprec = io->rprd; e.cldfrc = io->cld; e.landfrac = io->landfrac;
     e.prec = io->prec; e.tend_s = tend_s; e.tend_s_snwprd = snwprd; e.tend_s_snwevmlt = snwevmlt; e.tend_q = tend_q;
     e.ntprprd = ntprprd; e.ntsnprd = ntsnprd; e.flxprec = io->flxprec; e.flxsnow = io->flxsnow; e.snow = io->snow;
+    colphys_momtran_io m{};
+    m.winds = io->u; m.mu = io->mu; m.md = io->md; m.du = io->du; m.eu = io->eu; m.ed = io->ed; m.dp = io->dp;
+    m.dsubcld = io->dsubcld; m.jt = io->jt; m.mx = io->maxg; m.ideep = io->ideep; m.lengath = io->lengath;
+    m.dqdt = wtend; m.pguall = pguall; m.pgdall = pgdall; m.icwu = icwu; m.icwd = icwd; m.seten = seten;
+
+    // A small rank -- a strong-scaled share of the grid, a chunk-sized call -- is all launch latency from here on: the three
+    // stages that do not depend on each other go out as ONE launch, the last two updates and the last two geopotential_t as one
+    // each (colphys_common.h ZmTailSmall; bit-identical).  COLPHYS_TAIL_FUSED = 0 / 1 forces the choice (tests, A/B); the
+    // per-kernel timers of the measurement mode need the separate launches.
+    bool fused_tail = ncol <= 20000;
+    if (const char *ev = getenv("COLPHYS_TAIL_FUSED")) fused_tail = atoi(ev) != 0;
+    if (g_prof) fused_tail = false;
+    if (fused_tail) {
+        double *t2 = w.take<double>(nM), *zi_s = w.take<double>(nI), *zm_s = w.take<double>(nM);
+        ZmTailSmall T{};
+        T.ncol = ncol; T.pver = pver; T.pcols = pcols; T.dycore_kind = dycore_kind; T.ztodt = ztodt; T.qmin = qmin;
+        T.lnpint = io->lnpint; T.pint = io->pint; T.pmid = io->pmid; T.pdel = io->pdel; T.rpdel = io->rpdel; T.rair = io->rair; T.zvir = io->zvir;
+        T.t1 = t1; T.q1 = q1; T.u1 = u1; T.v1 = v1; T.zi1 = zi1; T.zm1 = zm1; T.t2 = t2; T.zi_scratch = zi_s; T.zm_scratch = zm_s;
+        T.u = io->u; T.v = io->v; T.evap = e; T.mom = m;
+        T.ptend_s = io->ptend_s; T.ptend_q = io->ptend_q; T.ptend_u = io->ptend_u; T.ptend_v = io->ptend_v;
+        rc = launch_zm_tail_small(g_P, g_estbl, T, st);
+        return rc ? fail(rc, "fused tail launch failed") : COLPHYS_OK;
+    }
+    if ((rc = geopotential())) return rc;
+
+    // ---- zm_conv_evap on state1 (:764-771); evapcdp = its dq/dt (:773) ----------------------------------------
     if ((rc = colphys_zm_conv_evap_dev(ncol, pver, ztodt, &e, stream))) return rc;
     if ((rc = update(t1, tend_s, q1, tend_q, nullptr, nullptr, nullptr, nullptr, 0))) return fail(rc, "physics_update launch failed");
     if ((rc = geopotential())) return rc;
 
     // ---- momtran on state1's winds (:814-836); u, v have not been touched yet, so state1 u, v = state u, v -------
-    colphys_momtran_io m{};
-    m.winds = io->u; m.mu = io->mu; m.md = io->md; m.du = io->du; m.eu = io->eu; m.ed = io->ed; m.dp = io->dp;
-    m.dsubcld = io->dsubcld; m.jt = io->jt; m.mx = io->maxg; m.ideep = io->ideep; m.lengath = io->lengath;
-    m.dqdt = wtend; m.pguall = pguall; m.pgdall = pgdall; m.icwu = icwu; m.icwd = icwd; m.seten = seten;
     {
         ProfScope ps(COLPHYS_K_MOMTRAN, st);
         if ((rc = launch_momtran(g_P, ncol, pver, pcols, ztodt, m, st, io->v))) return fail(rc, "momtran launch failed");

@@ -24,6 +24,18 @@
 #define SCAN_UNROLL 2
 #endif
 
+// Synchronisation of ONE wave with itself: LDS traffic of a wave executes in order, so lanes of the same wave see each other's
+// earlier LDS stores without a hardware barrier; what is needed is that the COMPILER neither moves LDS accesses across this point
+// nor keeps a value in a register that another lane has overwritten in LDS.  A wavefront-scope release / acquire fence pair is
+// that (and the s_waitcnt lgkmcnt(0) the memory model asks for); wave_barrier keeps the scheduler from reordering around it.
+// Unlike __syncthreads() it is legal under divergent control flow (no s_barrier is executed) and costs no barrier slot.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Parameters as the kernels see them: colphys_zm_params plus the values zm_convi derives
 // (zm_conv.F90:145-155).  Passed BY VALUE as a kernel argument (wave-uniform => SGPRs / scalar loads).
 struct ZmDev {
@@ -341,6 +353,24 @@ int launch_zm_conv_evap(const ZmDev &P, const double *estbl_dev, int ncol, int p
 // winds_v: v in its own [ncol][pver] array (then io.winds holds u only), or null for the stacked [2][ncol][pver] layout
 int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, const colphys_momtran_io &io, hipStream_t st,
                    const double *winds_v = nullptr);
+// The tail of zm_conv_tend for a SMALL rank (a strong-scaled share, a chunk-sized call: every launch is latency, not work), after
+// zm_convr and its first physics_update: geopotential_t (state1 after zm_convr), zm_conv_evap and momtran -- independent of each
+// other (zm_conv_intr.F90:739-826: momtran reads winds and mass fluxes the first two never touch) -- as ONE launch of
+// heterogeneous blocks; then the second and third physics_update as one element-wise launch, the second and third
+// geopotential_t as one batched launch.  Same kernels' bodies, same results bit for bit; 5 launches instead of 9.
+struct ZmTailSmall {
+    int ncol, pver, pcols, dycore_kind;
+    double ztodt, qmin;
+    // geopotential_t inputs of the state (pressure fields are the caller's, unchanged by the path)
+    const double *lnpint, *pint, *pmid, *pdel, *rpdel, *rair, *zvir;
+    double *t1, *q1, *u1, *v1, *zi1, *zm1;           // state1 (t1, q1 hold the state after the first update on entry)
+    double *t2, *zi_scratch, *zm_scratch;            // work: temperature after the second update, the second geopotential_t's heights
+    const double *u, *v;                             // state winds
+    colphys_zm_conv_evap_io evap;
+    colphys_momtran_io mom;                          // mom.winds = u, winds_v = v
+    double *ptend_s, *ptend_q, *ptend_u, *ptend_v;   // ptend_all (s, q hold the zm_convr contribution on entry)
+};
+int launch_zm_tail_small(const ZmDev &P, const double *estbl_dev, const ZmTailSmall &T, hipStream_t st);
 int launch_modal_aero_sw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);
 int launch_modal_aero_lw(const AeroDev &A, int ncol, int pver, const colphys_modal_aero_io &io, hipStream_t st);
 void aero_kernel_select(int sw_kind, int lw_kind);

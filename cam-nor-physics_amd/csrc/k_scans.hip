@@ -4,7 +4,7 @@
 //   geopotential_dse /root/reference/physics/geopotential.F90:29-150    the same from dry static energy (T is an output)
 //   zm_conv_evap     /root/reference/physics/zm_conv.F90:1712-1972      top-down precipitation flux / evaporation
 //   convtran         /root/reference/physics/zm_conv.F90:1976-2311      tracer transport on the gathered columns
-//   (momtran lives in k_momtran.hip)
+//   momtran          /root/reference/physics/zm_conv.F90:2315-2715      momentum transport on the gathered columns
 //
 // HBM layout is column-contiguous [ncol][pver]; the scans are serial in k and independent across columns, so
 // the mapping is one lane per column with the block's columns staged through LDS:
@@ -80,17 +80,16 @@ constexpr int GT = GEO_TILE;  // columns per block
 #endif
 constexpr int GNT = GEO_THREADS;   // threads per block: two waves move data (8 flat-index steps of a 32-column tile at L32), 32 lanes scan
 
-__global__ __launch_bounds__(GNT) void geopotential_kernel(int ncol, int pver, int dycore_kind, int nspecies,
-                                                         const double *__restrict__ piln, const double *__restrict__ pint,
-                                                         const double *__restrict__ pmid, const double *__restrict__ pdel,
-                                                         const double *__restrict__ rpdel, const double *__restrict__ t,
-                                                         const double *__restrict__ q, const double *__restrict__ rair,
-                                                         double gravit, const double *__restrict__ zvir,
-                                                         double *__restrict__ zi, double *__restrict__ zm)
+// body shared by geopotential_kernel and the fused tail launch of a small rank (zm_tail3_kernel): block `bid` of `nt` threads
+__device__ __forceinline__ void geopotential_body(int bid, int tid, int nt, double *smem, int ncol, int pver, int dycore_kind, int nspecies,
+                                                  const double *__restrict__ piln, const double *__restrict__ pint,
+                                                  const double *__restrict__ pmid, const double *__restrict__ pdel,
+                                                  const double *__restrict__ rpdel, const double *__restrict__ t,
+                                                  const double *__restrict__ q, const double *__restrict__ rair,
+                                                  double gravit, const double *__restrict__ zvir,
+                                                  double *__restrict__ zi, double *__restrict__ zm)
 {
-    CHAIN_PRIO();
-    extern __shared__ double smem[];
-    const int col0 = blockIdx.x * GT;
+    const int col0 = bid * GT;
     const int nc = min(GT, ncol - col0);
     const int pverp = pver + 1;
     const int ldp = ldk_of(pverp);
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(GNT) void geopotential_kernel(int ncol, int pver, i
     double *sZM = smem + GT * ldp;        // [GT][ldp]: dzm(k), then zm(k)
 
     const int n = nc * pver;
-    for (int i = threadIdx.x; i < n; i += GNT) {
+    for (int i = tid; i < n; i += nt) {
         const int c = i / pver, k = i - c * pver;              // 0-based level
         const size_t g = col0 * L + i;                         // flat index, mid-level fields
         const size_t gi = (size_t)(col0 + c) * LP + k;         // flat index, interface fields
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(GNT) void geopotential_kernel(int ncol, int pver, i
     }
     __syncthreads();
 
-    const int c = threadIdx.x;
+    const int c = tid;
     if (c < nc) {
         double zi_kp1 = 0.0;                                   // :207-209
         sZI[c * ldp + pver] = 0.0;
@@ -141,14 +140,28 @@ __global__ __launch_bounds__(GNT) void geopotential_kernel(int ncol, int pver, i
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nc * pverp; i += GNT) {
+    for (int i = tid; i < nc * pverp; i += nt) {
         const int cc = i / pverp, k = i - cc * pverp;
         zi[col0 * LP + i] = sZI[cc * ldp + k];
     }
-    for (int i = threadIdx.x; i < n; i += GNT) {
+    for (int i = tid; i < n; i += nt) {
         const int cc = i / pver, k = i - cc * pver;
         zm[col0 * L + i] = sZM[cc * ldp + k];
     }
+}
+
+__global__ __launch_bounds__(GNT) void geopotential_kernel(int ncol, int pver, int dycore_kind, int nspecies,
+                                                         const double *__restrict__ piln, const double *__restrict__ pint,
+                                                         const double *__restrict__ pmid, const double *__restrict__ pdel,
+                                                         const double *__restrict__ rpdel, const double *__restrict__ t,
+                                                         const double *__restrict__ q, const double *__restrict__ rair,
+                                                         double gravit, const double *__restrict__ zvir,
+                                                         double *__restrict__ zi, double *__restrict__ zm)
+{
+    CHAIN_PRIO();
+    extern __shared__ double smem[];
+    geopotential_body(blockIdx.x, threadIdx.x, GNT, smem, ncol, pver, dycore_kind, nspecies, piln, pint, pmid, pdel, rpdel, t, q, rair, gravit,
+                      zvir, zi, zm);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -253,13 +266,11 @@ __device__ __forceinline__ double kemask_of(const ZmDev &P, double landfrac)
 {   // :1860-1866: ke, or the land/ocean blend when zm_org
     return P.zm_org ? (P.ke * (1.0 - landfrac) + P.ke_lnd * landfrac) : P.ke;
 }      // threads per block: four waves move the tiles (4 flat-index steps per tile at L32), 32 lanes scan
-__global__ __launch_bounds__(ENT) void zm_conv_evap_kernel(ZmDev P, const double *__restrict__ estbl, int ncol, int pver,
-                                                         double deltat, colphys_zm_conv_evap_io io)
+// body shared by zm_conv_evap_kernel and zm_tail3_kernel (blocks of ENT threads either way)
+__device__ __forceinline__ void zm_conv_evap_body(int bid, double *smem, double *s_estbl, const ZmDev &P, const double *__restrict__ estbl,
+                                                  int ncol, int pver, double deltat, const colphys_zm_conv_evap_io &io)
 {
-    CHAIN_PRIO();
-    extern __shared__ double smem[];
-    __shared__ double s_estbl[COLPHYS_PLENEST + 1];
-    const int col0 = blockIdx.x * ETILE;
+    const int col0 = bid * ETILE;
     const int nc = min(ETILE, ncol - col0);
     const int pverp = pver + 1;
     const int ld = ldk_of(pver), ldp = ldk_of(pverp);
@@ -382,6 +393,15 @@ __global__ __launch_bounds__(ENT) void zm_conv_evap_kernel(ZmDev P, const double
     tile_out(io.ntsnprd + col0 * L, sCL, nc, pver, ld);
     tile_out(io.flxprec + col0 * LP, sFP, nc, pverp, ldp);
     tile_out(io.flxsnow + col0 * LP, sFS, nc, pverp, ldp);
+}
+
+__global__ __launch_bounds__(ENT) void zm_conv_evap_kernel(ZmDev P, const double *__restrict__ estbl, int ncol, int pver,
+                                                         double deltat, colphys_zm_conv_evap_io io)
+{
+    CHAIN_PRIO();
+    extern __shared__ double smem[];
+    __shared__ double s_estbl[COLPHYS_PLENEST + 1];
+    zm_conv_evap_body(blockIdx.x, smem, s_estbl, P, estbl, ncol, pver, deltat, io);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -593,6 +613,254 @@ __global__ __launch_bounds__(64) void convtran_wave_kernel(int ncol, int pver, i
 }
 
 // ------------------------------------------------------------------------------------------------------
+// momtran :2315-2715: convective momentum transport of u, v on the gathered (deep) columns.
+//
+// Only the gathered columns do work -- a few thousand of 48 602 -- so the mapping is ONE WAVE PER GATHERED COLUMN with the
+// lanes along the vertical.  A block serves one host chunk: its waves first write the initial values of the chunk's
+// full-layout outputs (:2429-2443), then share the chunk's gathered rows among themselves (wave w takes rows w, w + nw, ...;
+// round 3: a chunk with eight convecting columns used to walk them one after the other on a single wave, and the kernel took as
+// long as the fullest chunk).  Per row:
+//   - the column's profiles (winds, mass fluxes, layer thickness) are read as contiguous rows into the wave's LDS;
+//   - everything that is element-wise in k (interface winds, pressure-gradient terms, tendencies, momentum flux,
+//     end-of-step winds, KE dissipation) runs one level per lane;
+//   - the two genuine recurrences (in-cloud updraft wind, bottom-up :2563-2575; downdraft wind, top-down :2579-2589) are
+//     walked serially in the reference's order, in LDS, by lane 0 for u and lane 1 for v;
+//   - results leave as contiguous rows.
+// Waves synchronise with themselves only (wave_sync): rows of a chunk are independent.
+// ------------------------------------------------------------------------------------------------------
+constexpr int MOM_WAVES = 4;
+__host__ __device__ inline size_t momtran_lds_doubles_per_wave(int pver) { return (size_t)(6 + 2 * 8) * (pver + 2); }
+
+__device__ __forceinline__ void momtran_body(int bid, int tid, int nt, double *smem_block, const ZmDev &P, int ncol, int pver, int pcols, double dt,
+                                             const colphys_momtran_io &io, const double *winds_v)
+{
+    const int ic = bid, c0 = ic * pcols;
+    const int il2g = io.lengath[ic];
+    const size_t L = (size_t)pver, F = (size_t)ncol * L;
+    const double *wind[2] = {io.winds, winds_v ? winds_v : io.winds + F};   // u, v (v may live in its own array)
+    {   // initialisation of the chunk's full-layout outputs (:2429-2443): contiguous [nc][pver] runs, coalesced
+        const int nc = min(pcols, ncol - c0);
+        const size_t base = (size_t)c0 * L, n = (size_t)nc * L;
+        for (size_t i = tid; i < n; i += nt) {
+            for (int m = 0; m < 2; ++m) {
+                const size_t o = m * F + base + i;
+                const double w = wind[m][base + i];
+                io.pguall[o] = 0.0; io.pgdall[o] = 0.0; io.dqdt[o] = 0.0; io.icwu[o] = w; io.icwd[o] = w;
+            }
+            io.seten[base + i] = 0.0;
+        }
+    }
+    if (il2g <= 0) return;                                    // block-uniform
+    __syncthreads();                                          // the rows below overwrite parts of what was just initialised
+    const int lane = tid & (WAVE - 1), wave = tid >> 6, nw = nt >> 6;
+    const int LD = pver + 2;                                  // 1-based profiles, [0] and [pver+1] as guards
+    const double mbsth = 1.e-15;
+    double *smem = smem_block + (size_t)wave * momtran_lds_doubles_per_wave(pver);
+
+    double *s_mu = smem, *s_md = s_mu + LD, *s_du = s_md + LD, *s_eu = s_du + LD, *s_ed = s_eu + LD, *s_dp = s_ed + LD;
+    double *s_c = s_dp + LD;          // const   [2][LD]
+    double *s_chat = s_c + 2 * LD;    // chat    [2][LD]
+    double *s_conu = s_chat + 2 * LD; // conu    [2][LD]
+    double *s_cond = s_conu + 2 * LD; // cond    [2][LD]
+    double *s_pgu = s_cond + 2 * LD;  // pgu     [2][LD]
+    double *s_pgd = s_pgu + 2 * LD;   // pgd     [2][LD]
+    double *s_mf = s_pgd + 2 * LD;    // mflux   [2][LD]  (index pver+1 stays 0)
+    double *s_wf = s_mf + 2 * LD;     // windf   [2][LD]
+
+    int ktm = pver, kbm = pver;                                                  // :2449-2454 (per chunk)
+    for (int i = 0; i < il2g; ++i) {
+        ktm = min(ktm, io.jt[c0 + i]);
+        kbm = min(kbm, io.mx[c0 + i]);
+    }
+    for (int slot = wave; slot < il2g; slot += nw) {          // wave-uniform
+    const int row = c0 + slot;                                // gathered row of the flat layout
+    const size_t ii = (size_t)(c0 + io.ideep[row] - 1);
+    const int mx = io.mx[row];
+
+    for (int k = lane + 1; k <= pver; k += WAVE) {
+        const size_t g = (size_t)row * L + (k - 1);
+        s_mu[k] = io.mu[g]; s_md[k] = io.md[g]; s_du[k] = io.du[g]; s_eu[k] = io.eu[g]; s_ed[k] = io.ed[g]; s_dp[k] = io.dp[g];
+        for (int m = 0; m < 2; ++m) {
+            s_c[m * LD + k] = wind[m][ii * L + (k - 1)];                         // :2461-2466
+            s_mf[m * LD + k] = 0.0; s_wf[m * LD + k] = 0.0;                      // :2436-2438
+        }
+    }
+    if (lane < 2) { s_mf[lane * LD + pver + 1] = 0.0; s_mf[lane * LD] = 0.0; }
+    wave_sync();
+
+    for (int m = 0; m < 2; ++m) {
+        const double *cn = s_c + m * LD;
+        double *chat = s_chat + m * LD, *conu = s_conu + m * LD, *cond = s_cond + m * LD, *pgu = s_pgu + m * LD,
+               *pgd = s_pgd + m * LD;
+        for (int k = lane + 1; k <= pver; k += WAVE) {
+            const int km1 = max(1, k - 1);
+            const double ch = 0.5 * (cn[k] + cn[km1]);                           // :2473-2488
+            chat[k] = ch; conu[k] = ch; cond[k] = ch;
+            double gu, gd;
+            if (k == 1) {                                                        // :2497-2499
+                gu = 0.0; gd = 0.0;
+            } else if (k <= pver - 1) {                                          // :2501-2521
+                const int kp1 = k + 1;
+                const double mududp = (s_mu[k] * (cn[k] - cn[km1]) / s_dp[km1] + s_mu[kp1] * (cn[kp1] - cn[k]) / s_dp[k]);
+                gu = -P.momcu * 0.5 * mududp;
+                const double mddudp = (s_md[k] * (cn[k] - cn[km1]) / s_dp[km1] + s_md[kp1] * (cn[kp1] - cn[k]) / s_dp[k]);
+                gd = -P.momcd * 0.5 * mddudp;
+            } else {                                                             // :2524-2535
+                const double mududp = s_mu[k] * (cn[k] - cn[km1]) / s_dp[km1];
+                gu = -P.momcu * mududp;
+                const double mddudp = s_md[k] * (cn[k] - cn[km1]) / s_dp[km1];
+                gd = -P.momcd * mddudp;
+            }
+            pgu[k] = gu; pgd[k] = gd;
+        }
+    }
+    wave_sync();
+
+    // the two recurrences, serial in k: lane 0 walks them for u, lane 1 for v
+    if (lane < 2) {
+        const int m = lane;                                   // one component per lane: u on lane 0, v on lane 1
+        const double *cn = s_c + m * LD, *pgu = s_pgu + m * LD, *pgd = s_pgd + m * LD;
+        double *conu = s_conu + m * LD, *cond = s_cond + m * LD;
+        {                                                                        // :2543-2558
+            const int k = 2, km1 = 1, kk = pver;
+            const double mupdudp = s_mu[kk] + s_du[kk] * s_dp[kk];
+            if (mupdudp > mbsth) conu[kk] = (+s_eu[kk] * cn[kk] * s_dp[kk] + pgu[kk] * s_dp[kk]) / mupdudp;
+            // operator precedence of the reference kept as is (:2554)
+            if (s_md[k] < -mbsth) cond[k] = (-s_ed[km1] * cn[km1] * s_dp[km1]) - pgd[km1] * s_dp[km1] / s_md[k];
+        }
+#pragma unroll SCAN_UNROLL
+        for (int kk = pver - 1; kk >= 1; --kk) {                                 // :2563-2575
+            const double mupdudp = s_mu[kk] + s_du[kk] * s_dp[kk];
+            if (mupdudp > mbsth)
+                conu[kk] = (s_mu[kk + 1] * conu[kk + 1] + s_eu[kk] * cn[kk] * s_dp[kk] + pgu[kk] * s_dp[kk]) / mupdudp;
+        }
+#pragma unroll SCAN_UNROLL
+        for (int k = 3; k <= pver; ++k) {                                        // :2579-2589
+            const int km1 = k - 1;
+            if (s_md[k] < -mbsth)
+                cond[k] = (s_md[km1] * cond[km1] - s_ed[km1] * cn[km1] * s_dp[km1] - pgd[km1] * s_dp[km1]) / s_md[k];
+        }
+    }
+    wave_sync();
+
+    for (int m = 0; m < 2; ++m) {
+        const double *chat = s_chat + m * LD, *conu = s_conu + m * LD, *cond = s_cond + m * LD;
+        double *mf = s_mf + m * LD;
+        for (int k = lane + 1; k <= pver; k += WAVE) {
+            double dcondt = 0.0;
+            if (k >= ktm) {                                                      // :2596-2611
+                const int kp1 = min(pver, k + 1);
+                dcondt = +(s_mu[kp1] * (conu[kp1] - chat[kp1]) - s_mu[k] * (conu[k] - chat[k])
+                           + s_md[kp1] * (cond[kp1] - chat[kp1]) - s_md[k] * (cond[k] - chat[k])) / s_dp[k];
+                mf[k] = -s_mu[k] * (conu[k] - chat[k]) - s_md[k] * (cond[k] - chat[k]);       // :2646-2653
+            }
+            if (k >= kbm && k == mx)                                             // :2615-2627
+                dcondt = (1.0 / s_dp[k]) * (-s_mu[k] * (conu[k] - chat[k]) - s_md[k] * (cond[k] - chat[k]));
+            const size_t o = m * F + ii * L + (k - 1);                           // :2632-2642
+            io.dqdt[o] = dcondt; io.pguall[o] = -s_pgu[m * LD + k]; io.pgdall[o] = -s_pgd[m * LD + k];
+            io.icwu[o] = conu[k]; io.icwd[o] = cond[k];
+        }
+    }
+    wave_sync();
+    for (int m = 0; m < 2; ++m) {                                                // :2658-2666
+        const double *cn = s_c + m * LD, *mf = s_mf + m * LD;
+        for (int k = lane + 1; k <= pver; k += WAVE)
+            if (k >= ktm) s_wf[m * LD + k] = cn[k] - (mf[k + 1] - mf[k]) * dt / s_dp[k];
+    }
+    wave_sync();
+    for (int k = lane + 1; k <= pver; k += WAVE) {                               // :2675-2712
+        double gset = 0.0;
+        if (k >= ktm) {
+            const int km1 = max(1, k - 1), kp1 = min(pver, k + 1);
+            const double *w0u = s_c, *w0v = s_c + LD, *mfu = s_mf, *mfv = s_mf + LD, *wfu = s_wf, *wfv = s_wf + LD;
+            const double utop = (w0u[k] + w0u[km1]) / 2.0, vtop = (w0v[k] + w0v[km1]) / 2.0;
+            const double ubot = (w0u[kp1] + w0u[k]) / 2.0, vbot = (w0v[kp1] + w0v[k]) / 2.0;
+            const double fket = utop * mfu[k] + vtop * mfv[k];
+            const double fkeb = ubot * mfu[k + 1] + vbot * mfv[k + 1];
+            const double ketend_cons = (fket - fkeb) / s_dp[k];
+            const double ketend = ((wfu[k] * wfu[k] + wfv[k] * wfv[k]) - (w0u[k] * w0u[k] + w0v[k] * w0v[k])) * 0.5 / dt;
+            gset = ketend_cons - ketend;
+        }
+        io.seten[ii * L + (k - 1)] = gset;
+    }
+    wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(MOM_WAVES * WAVE) void momtran_wave_kernel(ZmDev P, int ncol, int pver, int pcols, double dt,
+                                                                       colphys_momtran_io io, const double *winds_v)
+{
+    CHAIN_PRIO();
+    extern __shared__ double smem[];
+    momtran_body(blockIdx.x, threadIdx.x, MOM_WAVES * WAVE, smem, P, ncol, pver, pcols, dt, io, winds_v);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The tail of zm_conv_tend for a small rank (colphys_common.h ZmTailSmall): one launch of heterogeneous blocks --
+// [0, ng) geopotential_t tiles, [ng, ng + ne) zm_conv_evap tiles, the rest one momtran block per host chunk -- each running
+// the body of the stand-alone kernel.  ENT threads per block; the dynamic LDS is the largest of the three.
+// ------------------------------------------------------------------------------------------------------
+struct Tail3Geo { int dycore_kind; const double *piln, *pint, *pmid, *pdel, *rpdel, *t, *q, *rair, *zvir; double gravit; double *zi, *zm; };
+__global__ __launch_bounds__(ENT) void zm_tail3_kernel(ZmDev P, const double *__restrict__ estbl, int ncol, int pver, int pcols, int ng, int ne,
+                                                     Tail3Geo G, double ztodt, colphys_zm_conv_evap_io E, colphys_momtran_io M,
+                                                     const double *winds_v)
+{
+    CHAIN_PRIO();
+    extern __shared__ double smem[];
+    __shared__ double s_estbl[COLPHYS_PLENEST + 1];
+    const int b = blockIdx.x;                                   // block-uniform dispatch
+    if (b < ng)
+        geopotential_body(b, threadIdx.x, ENT, smem, ncol, pver, G.dycore_kind, 1, G.piln, G.pint, G.pmid, G.pdel, G.rpdel, G.t, G.q, G.rair,
+                          G.gravit, G.zvir, G.zi, G.zm);
+    else if (b < ng + ne)
+        zm_conv_evap_body(b - ng, smem, s_estbl, P, estbl, ncol, pver, ztodt, E);
+    else
+        momtran_body(b - ng - ne, threadIdx.x, ENT, smem, P, ncol, pver, pcols, ztodt, M, winds_v);
+}
+
+// second and third physics_update of zm_conv_tend in one pass (zm_conv_intr.F90:802-806, 829-836), element-wise:
+//   t2 = t1 + evap_s dt/cp (kept: the second geopotential_t reads it),  q1 <- max(q1 + evap_q dt, qmin),
+//   t1 <- t2 + seten dt/cp,  u1 = u + du dt,  v1 = v + dv dt;  ptend_all += in the reference's order
+__global__ void physics_update23_kernel(size_t n, double dt, double cpair, double qmin, double *t1, double *t2, double *q1,
+                                        const double *__restrict__ evap_s, const double *__restrict__ evap_q,
+                                        const double *__restrict__ seten, const double *__restrict__ u, const double *__restrict__ v,
+                                        const double *__restrict__ du, const double *__restrict__ dv, double *u1, double *v1,
+                                        double *sum_s, double *sum_q, double *sum_u, double *sum_v)
+{
+    CHAIN_PRIO();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double es = evap_s[i], eq = evap_q[i], se = seten[i];
+        const double ta = t1[i] + es * dt / cpair;                         // physics_types.F90:427, second update
+        t2[i] = ta;
+        q1[i] = fmax(q1[i] + eq * dt, qmin);                               // :321, qneg3 :329
+        t1[i] = ta + se * dt / cpair;                                      // third update
+        u1[i] = u[i] + du[i] * dt;                                         // :295
+        v1[i] = v[i] + dv[i] * dt;                                         // :303
+        sum_s[i] = (sum_s[i] + es) + se;                                   // physics_ptend_sum, twice (zm_conv_intr.F90:802, 829)
+        sum_q[i] = sum_q[i] + eq;
+        sum_u[i] = du[i];
+        sum_v[i] = dv[i];
+    }
+}
+
+// second and third geopotential_t in one launch: blockIdx.y picks (t2 -> scratch heights) or (t1 -> zi1, zm1)
+__global__ __launch_bounds__(GNT) void geopotential_pair_kernel(int ncol, int pver, int dycore_kind, const double *__restrict__ piln,
+                                                              const double *__restrict__ pint, const double *__restrict__ pmid,
+                                                              const double *__restrict__ pdel, const double *__restrict__ rpdel,
+                                                              const double *__restrict__ t_a, const double *__restrict__ t_b,
+                                                              const double *__restrict__ q, const double *__restrict__ rair, double gravit,
+                                                              const double *__restrict__ zvir, double *zi_a, double *zm_a, double *zi_b,
+                                                              double *zm_b)
+{
+    CHAIN_PRIO();
+    extern __shared__ double smem[];
+    const bool second = blockIdx.y != 0;
+    geopotential_body(blockIdx.x, threadIdx.x, GNT, smem, ncol, pver, dycore_kind, 1, piln, pint, pmid, pdel, rpdel, second ? t_b : t_a, q, rair,
+                      gravit, zvir, second ? zi_b : zi_a, second ? zm_b : zm_a);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // physics_update (tendency application part), element-wise, grid-stride
 // ------------------------------------------------------------------------------------------------------
 __global__ void physics_update_kernel(size_t n, double dt, double cpair, double qmin, const double *__restrict__ t_in,
@@ -665,6 +933,39 @@ int launch_zm_conv_evap(const ZmDev &P, const double *estbl_dev, int ncol, int p
     if (set_lds((const void *)zm_conv_evap_kernel, lds)) return COLPHYS_ERR_HIP;
     const int nblk = (ncol + ETILE - 1) / ETILE;
     hipLaunchKernelGGL(zm_conv_evap_kernel, dim3(nblk), dim3(ENT), lds, st, P, estbl_dev, ncol, pver, deltat, io);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}
+
+int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, const colphys_momtran_io &io, hipStream_t st,
+                   const double *winds_v)
+{
+    const size_t lds = MOM_WAVES * momtran_lds_doubles_per_wave(pver) * sizeof(double);
+    if (set_lds((const void *)momtran_wave_kernel, lds)) return COLPHYS_ERR_HIP;
+    const int nchunks = (ncol + pcols - 1) / pcols;
+    hipLaunchKernelGGL(momtran_wave_kernel, dim3(nchunks), dim3(MOM_WAVES * WAVE), lds, st, P, ncol, pver, pcols, dt, io, winds_v);
+    return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
+}
+
+int launch_zm_tail_small(const ZmDev &P, const double *estbl_dev, const ZmTailSmall &T, hipStream_t st)
+{
+    const int ncol = T.ncol, pver = T.pver;
+    const int ld = (pver & 1) ? pver : pver + 1, ldp = ((pver + 1) & 1) ? pver + 1 : pver + 2;
+    const size_t lds_geo = (size_t)GT * 2 * ldp * sizeof(double), lds_evap = (size_t)ETILE * (6 * ld + 2 * ldp) * sizeof(double);
+    const size_t lds_mom = (ENT / WAVE) * momtran_lds_doubles_per_wave(pver) * sizeof(double);
+    const size_t lds = lds_geo > lds_evap ? (lds_geo > lds_mom ? lds_geo : lds_mom) : (lds_evap > lds_mom ? lds_evap : lds_mom);
+    if (lds > 150 * 1024) return COLPHYS_ERR_UNSUPPORTED;
+    if (set_lds((const void *)zm_tail3_kernel, lds)) return COLPHYS_ERR_HIP;
+    const int ng = (ncol + GT - 1) / GT, ne = (ncol + ETILE - 1) / ETILE, nm = (ncol + T.pcols - 1) / T.pcols;
+    Tail3Geo G{T.dycore_kind, T.lnpint, T.pint, T.pmid, T.pdel, T.rpdel, T.t1, T.q1, T.rair, T.zvir, P.gravit, T.zi1, T.zm1};
+    hipLaunchKernelGGL(zm_tail3_kernel, dim3(ng + ne + nm), dim3(ENT), lds, st, P, estbl_dev, ncol, pver, T.pcols, ng, ne, G, T.ztodt, T.evap,
+                       T.mom, T.v);
+    const size_t n = (size_t)ncol * pver;
+    const int nblk = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(physics_update23_kernel, dim3(nblk), dim3(256), 0, st, n, T.ztodt, P.cpair, T.qmin, T.t1, T.t2, T.q1, T.evap.tend_s,
+                       T.evap.tend_q, T.mom.seten, T.u, T.v, T.mom.dqdt, T.mom.dqdt + n, T.u1, T.v1, T.ptend_s, T.ptend_q, T.ptend_u, T.ptend_v);
+    if (set_lds((const void *)geopotential_pair_kernel, lds_geo)) return COLPHYS_ERR_HIP;
+    hipLaunchKernelGGL(geopotential_pair_kernel, dim3(ng, 2), dim3(GNT), lds_geo, st, ncol, pver, T.dycore_kind, T.lnpint, T.pint, T.pmid, T.pdel,
+                       T.rpdel, T.t2, T.t1, T.q1, T.rair, P.gravit, T.zvir, T.zi_scratch, T.zm_scratch, T.zi1, T.zm1);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
 

@@ -1467,25 +1467,26 @@ __global__ __launch_bounds__(WAVE) void zm_gather_kernel(int ncol, int pver, int
 {
     CHAIN_PRIO();
     __shared__ int s_src[1024];
-    __shared__ int s_n;
     const int c0 = blockIdx.x * pcols;
     const int nc = min(pcols, ncol - c0);
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (int i = 0; i < nc; ++i)
-            if (ws.deep[c0 + i]) { s_src[n] = i; ++n; }
-        s_n = n;
-        io.lengath[blockIdx.x] = n;
+    // ascending compaction by ballot: the block is one wave (round 3: lane 0 used to walk the chunk's columns one dependent
+    // load after the other -- 20 us of a latency-bound chain)
+    int n = 0;                                          // wave-uniform running count
+    for (int base = 0; base < nc; base += WAVE) {
+        const int i = base + (int)threadIdx.x;
+        const bool d = i < nc && ws.deep[c0 + i] != 0;
+        const unsigned long long m = __ballot(d);
+        if (d) s_src[n + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = i;
+        n += __popcll(m);
     }
+    if (threadIdx.x == 0) io.lengath[blockIdx.x] = n;
     __syncthreads();
-    const int n = s_n;
     const size_t L = (size_t)pver;
-    for (int j = 0; j < n; ++j) {
-        const size_t src = (size_t)(c0 + s_src[j]) * L, dst = (size_t)(c0 + j) * L;
-        for (int k = threadIdx.x; k < pver; k += blockDim.x) {
-            io.mu[dst + k] = ws.mu_f[src + k]; io.md[dst + k] = ws.md_f[src + k]; io.du[dst + k] = ws.du_f[src + k];
-            io.eu[dst + k] = ws.eu_f[src + k]; io.ed[dst + k] = ws.ed_f[src + k]; io.dp[dst + k] = ws.dp_f[src + k];
-        }
+    for (int idx = threadIdx.x; idx < n * pver; idx += blockDim.x) {
+        const int j = idx / pver, k = idx - j * pver;
+        const size_t src = (size_t)(c0 + s_src[j]) * L + k, dst = (size_t)(c0 + j) * L + k;
+        io.mu[dst] = ws.mu_f[src]; io.md[dst] = ws.md_f[src]; io.du[dst] = ws.du_f[src];
+        io.eu[dst] = ws.eu_f[src]; io.ed[dst] = ws.ed_f[src]; io.dp[dst] = ws.dp_f[src];
     }
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         const int src = c0 + s_src[j];

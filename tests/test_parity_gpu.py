@@ -1238,3 +1238,23 @@ def test_device_logarithms_within_one_ulp_class():
     ye = eng.math_probe("exp", eng.dev(xe)).cpu().numpy()
     re_ = np.exp(xe)
     assert (np.abs(ye - re_) / np.spacing(re_)).max() <= 2.0
+
+
+@pytest.mark.parametrize("pver,ncol", [(32, 6075), (70, 777), (32, 48602), (128, 130), (4, 50)])
+def test_zm_conv_tend_fused_tail_equals_separate_launches(pver, ncol, monkeypatch):
+    """A small rank runs the tail of zm_conv_tend as three launches (geopotential_t || zm_conv_evap || momtran as heterogeneous
+    blocks of one launch, the last two updates as one, the last two geopotential_t as one: ZmTailSmall) instead of nine; every
+    output, state1 and history field included, bit for bit the same either way, at sizes either side of the switch"""
+    eng = engine(cases.default_params(pver))
+    st = synth.make_state(ncol, pver, 909, moist_boost=1.1)
+    d = eng.dev
+    S = {k: d(st[k]) for k in abi.ZM_TEND_IN if k != "ps"}
+    S["ps"] = d(st["pint"][:, -1].copy())
+    monkeypatch.setenv("COLPHYS_TAIL_FUSED", "0")
+    a = to_np(eng.zm_conv_tend(S, synth.ZTODT, hist=True))
+    monkeypatch.setenv("COLPHYS_TAIL_FUSED", "1")
+    b = to_np(eng.zm_conv_tend(S, synth.ZTODT, hist=True))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    if pver >= 26:
+        assert a["lengath"].sum() > 0 and np.abs(a["ptend_u"]).max() > 0 and np.abs(a["evapcdp"]).max() > 0
