@@ -65,7 +65,7 @@ __device__ __forceinline__ double entropy_d(const ZmDev &P, double TK, double p,
     double qv = fmin(qtot, qst);
     double e = qv * p / (P.eps1 + qv);
     double lgp, lgq;
-    if (LPC == 2) {                         // the pair splits log((p - e)/pref) and log(qv/qst)
+    if (LPC >= 2) {                         // the pair splits log((p - e)/pref) and log(qv/qst)
         const double lg = cp_log((half ? qv : (p - e)) / (half ? qst : pref));
         const double lgo = pair_swap(lg);
         lgp = half ? lgo : lg;
@@ -109,9 +109,11 @@ __device__ __forceinline__ double enthalpy_d(const ZmDev &P, double TK, double p
 //  (5) LPC = 2: the function evaluation runs on a lane pair (colphys_common.h): same values, shorter chain.
 //  (6) the quotients of the evaluation and of Brent's interpolation step use fdiv (colphys_common.h): the compiler's
 //      own division sequence without its range pre-scaling, bit-identical for these operands, 3 instructions shorter.
+//  (7) LPC = 4: the two bracket evaluations that open the iteration run side by side on the two pairs of a lane quad
+//      (`side`; colphys_common.h quad_swap2): one evaluation less on the chain, same bits.
 template <int KIND, int LPC = 1>
 __device__ BRENT_INLINE int invert_brent(const ZmDev &P, double s, double p, double z, double qt, double &T, double &qst,
-                                         double Tfg, bool half = false)
+                                         double Tfg, bool half = false, bool side = false)
 {
     const int LOOPMAX = 100;
     const double EPS = 3.e-8;
@@ -154,8 +156,16 @@ __device__ BRENT_INLINE int invert_brent(const ZmDev &P, double s, double p, dou
 
     a = Tfg - 10;
     b = Tfg + 10;
-    fa = feval(a, qa);
-    fb = feval(b, qb);
+    if (LPC == 4) {
+        double q0;
+        const double f0 = feval(side ? b : a, q0);
+        const double fo = quad_swap2(f0), qo = quad_swap2(q0);
+        fa = side ? fo : f0; qa = side ? qo : q0;
+        fb = side ? f0 : fo; qb = side ? q0 : qo;
+    } else {
+        fa = feval(a, qa);
+        fb = feval(b, qb);
+    }
     c = b;
     fc = fb;
     qc = qb;
@@ -276,7 +286,8 @@ __device__ void buoyan_dilute_2w(const ZmDev &P, const ColIn &c, double pblt, do
 {
     const int pver = c.pver, msg = c.msg;
     const int npblt = (int)lrint(pblt);
-    const bool half = (LPC == 2) && (lane & 1);          // second lane of this column's pair (colphys_common.h)
+    const bool half = (LPC >= 2) && (lane & 1);          // second lane of a pair (colphys_common.h)
+    const bool side = (LPC == 4) && (lane & 2);          // second pair of this column's lane quad
     const double lwmax = 1.e-3, tscool = 0.0;
     double hmax = 0.0, pl, ql;
     int status = 0;
@@ -375,7 +386,7 @@ __device__ void buoyan_dilute_2w(const ZmDev &P, const ColIn &c, double pblt, do
         mp = mp - dmpdp * dp;
         const double smix1 = (sp0 + sp) / (mp0 + mp);
         qtmix = (qtp0 + qtp) / (mp0 + mp);
-        status |= invert_brent<1, LPC>(P, smix1, pk, zk, qtmix, tmix, qsmix, tmix1_kp1, half);
+        status |= invert_brent<1, LPC>(P, smix1, pk, zk, qtmix, tmix, qsmix, tmix1_kp1, half, side);
 
         if (qsmix <= qtmix && qsmix1_kp1 > qtmix_kp1) {             // LCL :5111-5133
             r.lcl = k;
@@ -389,7 +400,7 @@ __device__ void buoyan_dilute_2w(const ZmDev &P, const ColIn &c, double pblt, do
             const double slcl = smix1_kp1 + dsdp * (pl - p_kp1);
             const double qtlcl = qtmix_kp1 + dqtdp * (pl - p_kp1);
             double qslcl;
-            status |= invert_brent<1, LPC>(P, slcl, pl, zl, qtlcl, r.tl, qslcl, tmix, half);
+            status |= invert_brent<1, LPC>(P, slcl, pl, zl, qtlcl, r.tl, qslcl, tmix, half, side);
         }
         tmix1_kp1 = tmix; qsmix1_kp1 = qsmix; qtmix_kp1 = qtmix; smix1_kp1 = smix1;
         t_kp1 = tk; q_kp1 = qk; p_kp1 = pk; z_kp1 = zk;
@@ -420,7 +431,7 @@ __device__ void buoyan_dilute_2w(const ZmDev &P, const ColIn &c, double pblt, do
             new_s = smix2 + ds_xsh2o + ds_freeze;
             new_q = qtmix - xsh2o;
             const double tfguess = tmix;
-            status |= invert_brent<0, LPC>(P, new_s, pk, 0.0, new_q, tmix, qsmix, tfguess, half);
+            status |= invert_brent<0, LPC>(P, new_s, pk, 0.0, new_q, tmix, qsmix, tfguess, half, side);
         }
         xsh2o_kp1 = xsh2o; ds_xsh2o_kp1 = ds_xsh2o; ds_freeze_kp1 = ds_freeze; qsmix2_kp1 = qsmix;
 
@@ -592,7 +603,7 @@ __global__ __launch_bounds__(2 * TRIG_GROUPS_MAX * WAVE) void zm_trigger_kernel(
     const int bnb = min(TRIG_GROUPS * CPW, ncol - bcol0);           // columns of this block
     const int col = bcol0 + group * CPW + lane / LPC;
     const bool valid = col < ncol;
-    const bool first = (LPC == 1) || !(lane & 1);                   // the lane of a pair that stores the column's results
+    const bool first = (lane & (LPC - 1)) == 0;                     // the lane of a pair / quad that stores the column's results
     const size_t L = (size_t)pver, LP = (size_t)pver + 1;
     const int rows = pver + 2 - (P.limcnv - 1);               // the profile is only touched at levels > msg = limcnv - 1
     double *gmem = smem + (size_t)group * (rows * WAVE + MAIL_DOUBLES);
@@ -1297,7 +1308,7 @@ __global__ __launch_bounds__(2 * WAVE, CHAIN_WAVES_PER_SIMD) void zm_ascent2_ker
     if ((int)blockIdx.x * CPW >= count) return;                   // block-uniform
     const int gid = blockIdx.x * CPW + lane / LPC;
     const bool valid = gid < count;
-    const bool first = (LPC == 1) || !(lane & 1);
+    const bool first = (lane & (LPC - 1)) == 0;
     const int col = ws.list[valid ? gid : count - 1];             // lanes past the list shadow its last column
     const size_t L = (size_t)pver;
     const ColIn c = make_colin(P, io, col, pver);
@@ -1569,21 +1580,26 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     if (const char *e = getenv("COLPHYS_LPC_ASC")) lpc_asc_env = atoi(e);
     const int nblk32 = (ncol + 31) / 32;
     // ... unless its lane pairs still leave SIMDs idle: a chunk-sized call, or a rank's share of a strong-scaled grid
-    int lpc_trig = (2 * nblk32 <= n_simd) ? 2 : 1;
-    if (lpc_trig_env == 1 || lpc_trig_env == 2) lpc_trig = lpc_trig_env;
-    int lpc_asc = 2;
-    if (lpc_asc_env == 1 || lpc_asc_env == 2) lpc_asc = lpc_asc_env;
+    // lane quads (four lanes per column: the two bracket evaluations of every inversion side by side) while even four times the
+    // waves find a SIMD each: the trigger up to 8 192 columns, the second ascent -- ~20 % of the columns -- up to 24 000
+    // (round 3; a 6 075-column share: trigger 0.42 -> , second ascent 0.42 -> ms)
+    const int nblk16 = (ncol + 15) / 16;
+    int lpc_trig = (2 * nblk16 <= n_simd) ? 4 : ((2 * nblk32 <= n_simd) ? 2 : 1);
+    if (lpc_trig_env == 1 || lpc_trig_env == 2 || lpc_trig_env == 4) lpc_trig = lpc_trig_env;
+    int lpc_asc = ncol <= 24000 ? 4 : 2;
+    if (lpc_asc_env == 1 || lpc_asc_env == 2 || lpc_asc_env == 4) lpc_asc = lpc_asc_env;
     int groups = TRIG_GROUPS_MAX;
-    if (lpc_trig == 2) groups = 2;              // blocks of two pairs: three of them share a CU at three waves per SIMD
+    if (lpc_trig >= 2) groups = 2;              // blocks of two pairs: three of them share a CU at three waves per SIMD
     while (groups > 1 && lds2 * groups > 158 * 1024) groups /= 2;
     if (lds2 * groups > 160 * 1024) paired = false;
     if (paired) {
         const int cpb = groups * (WAVE / lpc_trig);
         const int ntrig = (ncol + cpb - 1) / cpb;
         const size_t ldst = lds2 * groups;
-        const void *fn = lpc_trig == 2 ? (const void *)zm_trigger_kernel<2> : (const void *)zm_trigger_kernel<1>;
+        const void *fn = lpc_trig == 4 ? (const void *)zm_trigger_kernel<4> : (lpc_trig == 2 ? (const void *)zm_trigger_kernel<2> : (const void *)zm_trigger_kernel<1>);
         if (ldst > 64 * 1024) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);
-        if (lpc_trig == 2) hipLaunchKernelGGL(zm_trigger_kernel<2>, dim3(ntrig), dim3(2 * groups * WAVE), ldst, st, P, ncol, pver, groups, io, ws);
+        if (lpc_trig == 4) hipLaunchKernelGGL(zm_trigger_kernel<4>, dim3(ntrig), dim3(2 * groups * WAVE), ldst, st, P, ncol, pver, groups, io, ws);
+        else if (lpc_trig == 2) hipLaunchKernelGGL(zm_trigger_kernel<2>, dim3(ntrig), dim3(2 * groups * WAVE), ldst, st, P, ncol, pver, groups, io, ws);
         else hipLaunchKernelGGL(zm_trigger_kernel<1>, dim3(ntrig), dim3(2 * groups * WAVE), ldst, st, P, ncol, pver, groups, io, ws);
     } else {
         if (lds > 160 * 1024) return COLPHYS_ERR_UNSUPPORTED;
@@ -1603,7 +1619,10 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     if (cpwv == 2) hipLaunchKernelGGL(zm_plume1_kernel<2>, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, io, ws);
     else hipLaunchKernelGGL(zm_plume1_kernel<1>, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, io, ws);
     if (ev) { hipEventRecord(ev[3], st); hipEventRecord(ev[4], st); }
-    if (lpc_asc == 2) {
+    if (lpc_asc == 4) {
+        if (lds2 > 64 * 1024) hipFuncSetAttribute((const void *)zm_ascent2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        hipLaunchKernelGGL(zm_ascent2_kernel<4>, dim3(nblk16), dim3(2 * WAVE), lds2, st, P, ncol, pver, io, ws);
+    } else if (lpc_asc == 2) {
         if (lds2 > 64 * 1024) hipFuncSetAttribute((const void *)zm_ascent2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         hipLaunchKernelGGL(zm_ascent2_kernel<2>, dim3(nblk32), dim3(2 * WAVE), lds2, st, P, ncol, pver, io, ws);
     } else {

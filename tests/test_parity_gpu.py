@@ -61,7 +61,7 @@ def check_zm(o, ref, ncol, pcols=cases.PCOLS):
 # ---------------------------------------------------------------------------------------------------
 # (a) golden fixtures = outputs of the reference Fortran
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("trig_mode", ["auto", "one-lane", "fused", "plume-pairs"])
+@pytest.mark.parametrize("trig_mode", ["auto", "lane-pairs", "one-lane", "fused", "plume-pairs"])
 @pytest.mark.parametrize("name", cases.ZM_GOLDEN)
 def test_zm_convr_vs_reference_golden(name, trig_mode, monkeypatch):
     """both mappings of the first ascent: wave pairs (what these column counts select) and the single-wave kernel
@@ -69,7 +69,11 @@ def test_zm_convr_vs_reference_golden(name, trig_mode, monkeypatch):
     two columns per wave, which large column counts at up to 32 levels select (forced through COLPHYS_PLUME_CPW; L70 keeps
     one column per wave whatever the setting)"""
     if trig_mode == "one-lane":                       # the wave-pair trigger with one lane per column (what > 16 384 columns select;
-        monkeypatch.setenv("COLPHYS_LPC_TRIG", "1")   # these column counts take two lanes per column by themselves)
+        monkeypatch.setenv("COLPHYS_LPC_TRIG", "1")   # these column counts take four lanes per column by themselves: "auto")
+        monkeypatch.setenv("COLPHYS_LPC_ASC", "2")
+    if trig_mode == "lane-pairs":                     # two lanes per column in both ascents (8 192 to 16 384 columns / beyond 24 000)
+        monkeypatch.setenv("COLPHYS_LPC_TRIG", "2")
+        monkeypatch.setenv("COLPHYS_LPC_ASC", "2")
     if trig_mode == "fused":
         monkeypatch.setenv("COLPHYS_TRIG_MODE", "2")
     if trig_mode == "plume-pairs":
@@ -1258,3 +1262,22 @@ def test_zm_conv_tend_fused_tail_equals_separate_launches(pver, ncol, monkeypatc
         assert np.array_equal(a[k], b[k]), k
     if pver >= 26:
         assert a["lengath"].sum() > 0 and np.abs(a["ptend_u"]).max() > 0 and np.abs(a["evapcdp"]).max() > 0
+
+
+def test_lane_quads_pairs_and_single_lanes_give_the_same_bits(monkeypatch):
+    """The dilute ascents with one, two or four lanes per column (colphys_common.h: lane pairs split the independent
+    transcendentals of a function evaluation, lane quads also run the two opening evaluations of every inversion side by side)
+    are the same operations on the same values: every output of zm_convr identical, at a strong-scaled share's size"""
+    pver, ncol = 32, 6075
+    eng = engine(cases.default_params(pver))
+    st = synth.make_state(ncol, pver, 4404, moist_boost=1.1)
+    args = cases.zm_args_from_state(st, st["zi"], st["zm"])
+    outs = {}
+    for lpc in ("1", "2", "4"):
+        monkeypatch.setenv("COLPHYS_LPC_TRIG", lpc)
+        monkeypatch.setenv("COLPHYS_LPC_ASC", lpc)
+        outs[lpc] = run_zm(eng, args)
+    assert outs["1"]["lengath"].sum() > 0.1 * ncol
+    for lpc in ("2", "4"):
+        for k, v in outs["1"].items():
+            assert np.array_equal(outs[lpc][k], v), (lpc, k)
