@@ -38,6 +38,14 @@ def build_hip(force: bool = False, verbose: bool = False, extra_flags=(), out: s
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
+    # the same flags, device side to assembly: refuse a build the backend miscompiled (isa_check.py; ~20 s)
+    from . import isa_check
+    hits = isa_check.check_sources(extra_flags)
+    if hits and out is None:
+        raise RuntimeError("hipcc left vector instructions in front of a loop-exit block's EXEC restore (they run with EXEC = 0):\n"
+                           + isa_check.format_hits(hits) + "\nno library was linked; see cam_nor_physics_amd/isa_check.py")
+    if hits:
+        print("isa_check (experiment build, linked anyway):\n" + isa_check.format_hits(hits))
     lib = out or LIB
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
     if verbose:

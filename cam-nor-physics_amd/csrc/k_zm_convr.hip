@@ -699,7 +699,14 @@ __global__ __launch_bounds__(WAVE) void zm_trigger_fused_kernel(ZmDev P, int nco
 // masks.  A block is one wave, so SYNC() inside such a branch is safe: LDS operations of a wave complete in order.
 // ------------------------------------------------------------------------------------------------------
 #define PAR(k, lo, hi) for (int k = (lo) + lane; k <= (hi); k += PSTEP)      // PSTEP: lanes per column (template parameter in scope)
+// A plume block is ONE wave: SYNC() orders the wave's own LDS traffic (colphys_common.h wave_sync).  It used to be __syncthreads(),
+// i.e. an s_barrier executed under whatever EXEC mask a divergent branch of the two-columns-per-wave mode had left -- harmless
+// for a one-wave workgroup in practice, but outside what HIP defines; -DPLUME_SYNC_BARRIER restores it (scripts/plume_hazard.sh).
+#ifdef PLUME_SYNC_BARRIER
 #define SYNC() __syncthreads()
+#else
+#define SYNC() wave_sync()
+#endif
 
 constexpr int PLUME_NARR = 49;
 #ifndef SERIAL_UNROLL
@@ -1145,7 +1152,13 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
                 const double qdkp1 = A.qds[k + 1];
                 A.qd[k + 1] = qdkp1;
                 const double edk = A.ed[k], qk = A.q[k], dzk = A.dz[k], mdk = A.md[k], mdkp1 = A.md[k + 1];
+#ifdef PLUME_QDSD_LDS                    // experiment (scripts/plume_hazard.sh): round 2's form, the recurrence read back through LDS.
+                                         // It is as correct as the register carry; it merely was the allocation under which hipcc
+                                         // miscompiled zm_plume2_kernel<2> (isa_check.py), which round 2 took for an LDS hazard.
+                const double qdk = A.qd[k], sdk = A.sd[k];
+#else
                 const double qdk = carried ? qd_c : A.qd[k], sdk = carried ? sd_c : A.sd[k];
+#endif
                 double evpk = -edk * qk + (mdk * qdk - mdkp1 * qdkp1) / dzk;
                 evpk = fmax(evpk, 0.0);
                 A.evp[k] = evpk;
@@ -1157,6 +1170,9 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
             } else {
                 carried = false;
             }
+#ifdef PLUME_QDSD_SYNC
+            SYNC();
+#endif
         }
     }
     totevp = totevp + A.md[jd] * A.qd[jd] - A.md[jb] * A.qd[jb];                             // :3974

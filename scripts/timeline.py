@@ -23,7 +23,9 @@ for r in rows:
 # bench.py: one eager substep (workspace allocation), then warmup + steps graph replays, then eager passes: keep the
 # graph replays only (dispatches 1 .. nreplay), minus the first `skip`
 nrep = int(sys.argv[3]) if len(sys.argv) > 3 else 12
-steps = [s for s in steps if len(s) == max(len(x) for x in steps)][1 + skip:1 + nrep]
+# the graph replays are the most frequent step shape (eager warm-up and the per-kernel timing passes launch other kernel sets)
+shape = collections.Counter(tuple(n for n, *_ in s) for s in steps).most_common(1)[0][0]
+steps = [s for s in steps if tuple(n for n, *_ in s) == shape][skip:nrep]
 def keyed(step):
     seen, out = collections.Counter(), {}
     for n, a, b, q in step:
