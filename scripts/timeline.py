@@ -23,9 +23,12 @@ for r in rows:
 # bench.py: one eager substep (workspace allocation), then warmup + steps graph replays, then eager passes: keep the
 # graph replays only (dispatches 1 .. nreplay), minus the first `skip`
 nrep = int(sys.argv[3]) if len(sys.argv) > 3 else 12
-# the graph replays are the most frequent step shape (eager warm-up and the per-kernel timing passes launch other kernel sets)
-shape = collections.Counter(tuple(n for n, *_ in s) for s in steps).most_common(1)[0][0]
-steps = [s for s in steps if tuple(n for n, *_ in s) == shape][skip:nrep]
+# the graph replays: the steps whose kernels ran on more than one queue (ZM chain || optics); a capture without the second
+# stream has none, then the most frequent kernel multiset (eager warm-up and the per-kernel timing passes launch other sets)
+multi = [s for s in steps if len({q for *_, q in s}) > 1]
+pool = multi or steps
+shape = collections.Counter(tuple(sorted(n for n, *_ in s)) for s in pool).most_common(1)[0][0]
+steps = [s for s in pool if tuple(sorted(n for n, *_ in s)) == shape][skip:nrep]
 def keyed(step):
     seen, out = collections.Counter(), {}
     for n, a, b, q in step:
