@@ -1485,8 +1485,9 @@ void oracle_geopotential_dse(int ncol, int pver, int dycore_kind, int nq, int ns
 
 /* ------------------------------------------------------------------------------------------------
  * convect_diagnostics_calc  /root/reference/physics/convect_diagnostics.F90:115-249
- * (parity unpinned against a reference BUILD: the module needs physics_types / physics_buffer of the parent model;
- *  this is a line-by-line restatement of :178-231, checked in tests/ against an independent numpy restatement)
+ * (a line-by-line restatement of :178-231.  Pinned since round 3: the reference's convect_diagnostics.F90 is built
+ *  unmodified with its real physics_types into oracle/_ref/liboracle_refintr_*.so (oracle/ref_wrap_intr.F90) and this
+ *  function is checked against its goldens tests/golden/intr_l{32,70}.npz in tests/test_oracle_vs_golden.py)
  * ---------------------------------------------------------------------------------------------- */
 void oracle_convect_diagnostics(int ncol, int pver, int clubb, const colphys_convect_diag_io *io)
 {
