@@ -66,6 +66,15 @@ module colphys_c_api
     type(c_ptr) :: vis_optics = c_null_ptr
   end type colphys_modal_aero_io
 
+  ! ---- host face (include/colphys.h "HOST FACE") ----
+  integer(c_int), parameter :: COLPHYS_HF_ZM = 1, COLPHYS_HF_AERO = 2, COLPHYS_HF_SWDIAG = 4, COLPHYS_HF_HIST = 8
+  type, bind(C) :: colphys_hostface_times
+     real(c_double) :: wall_ms, host_cpu_ms, h2d_ms, relayout_ms, physics_ms, d2h_ms
+     integer(c_int64_t) :: h2d_bytes, d2h_bytes
+     integer(c_int32_t) :: nslices, nstreams
+  end type colphys_hostface_times
+
+
   interface
     integer(c_int) function colphys_device_count() bind(C, name='colphys_device_count')
       import
@@ -161,6 +170,49 @@ module colphys_c_api
       real(c_double), value :: dt
       type(colphys_convtran_io), intent(in) :: io
     end function
+     integer(c_int) function colphys_hostface_create(nchunks, pcols, pver, ncol, what, nslices, hf) bind(C, name='colphys_hostface_create')
+       import
+       integer(c_int), value :: nchunks, pcols, pver, what, nslices
+       integer(c_int32_t), intent(in) :: ncol(*)
+       type(c_ptr), intent(out) :: hf
+     end function
+     integer(c_int) function colphys_hostface_destroy(hf) bind(C, name='colphys_hostface_destroy')
+       import
+       type(c_ptr), value :: hf
+     end function
+     integer(c_int) function colphys_hostface_geometry(hf, in_rec, out_rec, nfields) bind(C, name='colphys_hostface_geometry')
+       import
+       type(c_ptr), value :: hf
+       integer(c_int64_t), intent(out) :: in_rec, out_rec
+       integer(c_int32_t), intent(out) :: nfields
+     end function
+     integer(c_int) function colphys_hostface_field(hf, i, name, nlev, is_int, is_out, offset) bind(C, name='colphys_hostface_field')
+       import
+       type(c_ptr), value :: hf
+       integer(c_int), value :: i
+       character(kind=c_char), intent(out) :: name(32)
+       integer(c_int32_t), intent(out) :: nlev, is_int, is_out
+       integer(c_int64_t), intent(out) :: offset
+     end function
+     type(c_ptr) function colphys_hostface_in_base(hf) bind(C, name='colphys_hostface_in_base')
+       import
+       type(c_ptr), value :: hf
+     end function
+     type(c_ptr) function colphys_hostface_out_base(hf) bind(C, name='colphys_hostface_out_base')
+       import
+       type(c_ptr), value :: hf
+     end function
+     integer(c_int) function colphys_hostface_run(hf, ztodt, dycore_kind, qmin) bind(C, name='colphys_hostface_run')
+       import
+       type(c_ptr), value :: hf
+       real(c_double), value :: ztodt, qmin
+       integer(c_int), value :: dycore_kind
+     end function
+     integer(c_int) function colphys_hostface_last_times(hf, t) bind(C, name='colphys_hostface_last_times')
+       import
+       type(c_ptr), value :: hf
+       type(colphys_hostface_times), intent(out) :: t
+     end function
   end interface
 
 contains

@@ -55,6 +55,10 @@ module AER_MODULE
   save
 
   public :: modal_aer_opt_readnl, modal_aer_opt_init, modal_aero_sw, modal_aero_lw
+  ! whole-rank dispatch (not part of the reference's surface; the optics' half of the host face, colphys_hostface_mod.F90
+  ! being the convection step's): every chunk pushed, ONE run, every chunk pulled
+  public :: modal_aero_rank_init, modal_aero_rank_final, modal_aero_rank_push, modal_aero_rank_run, modal_aero_rank_pull_sw, &
+            modal_aero_rank_pull_lw
 
   integer, parameter :: ncoef = 5, prefr = 7, prefi = 10            ! modal_aer_opt.F90:56
   character(len=*), parameter :: unset_str = 'UNSET'
@@ -65,6 +69,19 @@ module AER_MODULE
   integer, parameter :: nerrmax_dopaer = 1000                       ! :619, :1275
   integer :: nerr_dopaer_sw = 0, nerr_dopaer_lw = 0                 ! :620 (modal_aero_sw's), :1276 (modal_aero_lw's)
   integer(c_int32_t), allocatable, target :: nspec_m(:)
+
+  ! field order of the engine's packed SW diagnostics (include/colphys.h COLPHYS_SWD_*)
+  integer, parameter :: nlevf = 5, ncolf0 = 23
+
+  ! ---- whole-rank dispatch: the host face's handle and the record offsets of the fields this module moves ----------------
+  type(c_ptr) :: hf = c_null_ptr
+  integer :: nchunks_rank = 0
+  integer, allocatable :: ncol_rank(:)
+  integer(c_intptr_t) :: in_base = 0, out_base = 0
+  integer(c_int64_t)  :: in_rec = 0, out_rec = 0
+  integer(c_int64_t)  :: off_t = -1, off_pmid = -1, off_pdeldry = -1, off_troplev = -1
+  integer(c_int64_t), allocatable :: off_dgn(:), off_qaw(:), off_mmr(:,:)              ! (mode), (mode), (species, mode)
+  integer(c_int64_t)  :: off_sw(4) = -1, off_lw = -1, off_swst = -1, off_lwst = -1, off_swdlev = -1, off_swdcol = -1
 
 contains
 
@@ -336,26 +353,12 @@ contains
     real(r8), intent(out), target :: ga(pcols,0:pver,nswbands)
     real(r8), intent(out), target :: fa(pcols,0:pver,nswbands)
 
-    ! field order of the engine's packed diagnostics (include/colphys.h COLPHYS_SWD_*)
-    integer, parameter :: nlevf = 5, ncolf0 = 23
-    character(len=16), parameter :: lev_names(nlevf) = (/ 'EXTINCT   ', 'ABSORB    ', 'EXTxASYM  ', 'EXTINCTUV ', 'EXTINCTNIR' /)
-    character(len=16), parameter :: col_names(ncolf0) = (/ &
-         'AODVIS       ', 'AODABS       ', 'AODTOT       ', 'AODVISst     ', 'SSAVIS       ', 'AODxASYM     ', 'AODUV        ', &
-         'AODNIR       ', 'AODUVst      ', 'AODNIRst     ', 'BURDENSO4    ', 'BURDENPOM    ', 'BURDENSOA    ', 'BURDENBC     ', &
-         'BURDENDUST   ', 'BURDENSEASALT', 'AODABSBC     ', 'AODSO4       ', 'AODPOM       ', 'AODSOA       ', 'AODBC        ', &
-         'AODDUST      ', 'AODSS        ' /)
-    ! outfld order of the reference: the seven summed visible-band fields (:1094-1118), then the climate-list set (:1130-1209)
-    integer, parameter :: first_set(7)  = (/ 101, 102, 1, 2, 3, 4, 103 /)            ! 100 + level field, else column field
-    integer, parameter :: first_set_day(7) = (/ 101, 102, 1, 3, 2, 4, 103 /)         ! the day-only set swaps AODTOT and AODABS (:1112-1118)
-    integer, parameter :: second_set(23) = (/ 5, 6, 104, 105, 7, 8, 9, 10, 15, 11, 12, 13, 14, 16, 17, 22, 18, 19, 20, 21, 23, 0, 0 /)
-
     real(c_double), allocatable, target :: pdeldry(:,:), specmmr(:,:,:,:), dgnumwet(:,:,:), qaerwat(:,:,:)
     real(c_double), allocatable, target :: pmid(:,:), t(:,:), dlev(:,:,:), dcol(:,:)
     integer(c_int32_t), target :: status(pcols), troplevchem(pcols)
     integer(c_int32_t) :: ncol_c(1)
     type(colphys_modal_aero_io) :: io
-    integer :: rc, ncol, lchnk, m, i, j, f
-    character(len=32) :: outname, modename
+    integer :: rc, ncol, lchnk
 
     ncol = state%ncol; lchnk = state%lchnk
     allocate(pdeldry(pcols,pver), specmmr(pcols,pver,max(nspec_max,1),max(nmodes_clim,1)), &
@@ -376,7 +379,30 @@ contains
     if (rc /= COLPHYS_OK) call endrun('modal_aero_sw (colphys): '//trim(colphys_error_message()))
     call check_status('modal_aero_sw', lchnk, ncol, status, nerr_dopaer_sw, -1)
 
-    ! ---- history output, as the reference orders it ---------------------------------------------------------
+    call sw_history_out(lchnk, ncol, nnite, idxnite, dlev, dcol)
+  end subroutine modal_aero_sw
+
+  !---------------------------------------------------------------------------------------------------------
+  ! What modal_aero_sw hands to outfld (:1046-1209), from the engine's packed diagnostics: dlev (pcols,pver,COLPHYS_SWD_NLEV),
+  ! dcol (pcols, COLPHYS_SWD_NCOL + 3 nmodes).  Night-column fill and the order of the calls are the reference's.
+  subroutine sw_history_out(lchnk, ncol, nnite, idxnite, dlev, dcol)
+    integer, intent(in) :: lchnk, ncol, nnite
+    integer, intent(in) :: idxnite(nnite)
+    real(r8), intent(inout) :: dlev(pcols,pver,nlevf), dcol(pcols,ncolf0+3*max(nmodes_clim,1))
+    character(len=16), parameter :: lev_names(nlevf) = (/ 'EXTINCT   ', 'ABSORB    ', 'EXTxASYM  ', 'EXTINCTUV ', 'EXTINCTNIR' /)
+    character(len=16), parameter :: col_names(ncolf0) = (/ &
+         'AODVIS       ', 'AODABS       ', 'AODTOT       ', 'AODVISst     ', 'SSAVIS       ', 'AODxASYM     ', 'AODUV        ', &
+         'AODNIR       ', 'AODUVst      ', 'AODNIRst     ', 'BURDENSO4    ', 'BURDENPOM    ', 'BURDENSOA    ', 'BURDENBC     ', &
+         'BURDENDUST   ', 'BURDENSEASALT', 'AODABSBC     ', 'AODSO4       ', 'AODPOM       ', 'AODSOA       ', 'AODBC        ', &
+         'AODDUST      ', 'AODSS        ' /)
+    ! outfld order of the reference: the seven summed visible-band fields (:1094-1118), then the climate-list set (:1130-1209)
+    integer, parameter :: first_set(7)  = (/ 101, 102, 1, 2, 3, 4, 103 /)            ! 100 + level field, else column field
+    integer, parameter :: first_set_day(7) = (/ 101, 102, 1, 3, 2, 4, 103 /)         ! the day-only set swaps AODTOT and AODABS (:1112-1118)
+    integer, parameter :: second_set(23) = (/ 5, 6, 104, 105, 7, 8, 9, 10, 15, 11, 12, 13, 14, 16, 17, 22, 18, 19, 20, 21, 23, 0, 0 /)
+
+    integer :: m, i, j
+    character(len=32) :: outname, modename
+
     do m = 1, nmodes_clim                                                           ! :1046-1074
       call rad_cnst_get_info(0, m, mode_type=modename)
       j = ncolf0 + 3*(m-1)
@@ -425,7 +451,7 @@ contains
         end if
       end do
     end subroutine put_set
-  end subroutine modal_aero_sw
+  end subroutine sw_history_out
 
   !---------------------------------------------------------------------------------------------------------
   subroutine modal_aero_lw(list_idx, state, pbuf, tauxar)
@@ -455,5 +481,180 @@ contains
     if (rc /= COLPHYS_OK) call endrun('modal_aero_lw (colphys): '//trim(colphys_error_message()))
     call check_status('modal_aero_lw', state%lchnk, state%ncol, status, nerr_dopaer_lw, nerrmax_dopaer)
   end subroutine modal_aero_lw
+
+  !=========================================================================================================
+  ! Whole-rank dispatch of the optics (the host face, include/colphys.h colphys_hostface_*; DESIGN.md 3).
+  !
+  ! What the radiation driver's chunk loop becomes (upstream aer_rad_props calls modal_aero_sw / modal_aero_lw per chunk,
+  ! modal_aer_opt.F90:485, 1216):
+  !     call modal_aero_rank_init(ncol)                                   ! once, after modal_aer_opt_init
+  !     do c: call modal_aero_rank_push(c, state(c), pbuf_c)              ! the accessors of :679-681, 717-762 per chunk; copies only
+  !     call modal_aero_rank_run()                                        ! ONE dispatch: SW, its history diagnostics, LW, all chunks
+  !     do c: call modal_aero_rank_pull_sw(c, state(c), nnite, idxnite, tauxar, wa, ga, fa)   ! + the outfld calls of :1046-1209
+  !           call modal_aero_rank_pull_lw(c, state(c), tauxar_lw)
+  ! Records are the (pcols, nlev) arrays of the chunk in pinned memory the library owns; pushes and pulls of distinct chunks
+  ! may run concurrently (the counters nerr_dopaer_* are shared, as the reference's SAVEd ones are).
+  !=========================================================================================================
+  subroutine rank_fail(what)
+    character(len=*), intent(in) :: what
+    call endrun('modal_aero_rank (colphys): '//what//': '//trim(colphys_error_message()))
+  end subroutine rank_fail
+
+  subroutine modal_aero_rank_init(ncol)
+    integer, intent(in) :: ncol(:)                       ! active columns of the rank's chunks, begchunk .. endchunk
+    integer(c_int32_t) :: nc(size(ncol)), nf, nlev, is_int, is_out
+    integer(c_int64_t) :: off
+    character(kind=c_char) :: cname(32)
+    character(len=32) :: name
+    integer :: i, j, m, l
+    if (nmodes_clim <= 0) call endrun('modal_aero_rank_init (colphys): modal_aer_opt_init has not been called')
+    if (c_associated(hf)) call modal_aero_rank_final()
+    nc = ncol
+    nchunks_rank = size(ncol)
+    allocate(ncol_rank(nchunks_rank)); ncol_rank = ncol
+    allocate(off_dgn(nmodes_clim), off_qaw(nmodes_clim), off_mmr(max(nspec_max,1), nmodes_clim))
+    off_dgn = -1; off_qaw = -1; off_mmr = -1
+    if (colphys_hostface_create(nchunks_rank, pcols, pver, nc, COLPHYS_HF_AERO + COLPHYS_HF_SWDIAG, 0, hf) /= 0) call rank_fail('colphys_hostface_create')
+    if (colphys_hostface_geometry(hf, in_rec, out_rec, nf) /= 0) call rank_fail('colphys_hostface_geometry')
+    do i = 1, nf
+      if (colphys_hostface_field(hf, i - 1, cname, nlev, is_int, is_out, off) /= 0) call rank_fail('colphys_hostface_field')
+      name = ' '
+      do j = 1, 32
+        if (cname(j) == c_null_char) exit
+        name(j:j) = cname(j)
+      end do
+      select case (trim(name))
+      case ('t');           off_t = off
+      case ('pmid');        off_pmid = off
+      case ('pdeldry');     off_pdeldry = off
+      case ('troplevchem'); off_troplev = off
+      case ('sw_tauxar');   off_sw(1) = off
+      case ('sw_wa');       off_sw(2) = off
+      case ('sw_ga');       off_sw(3) = off
+      case ('sw_fa');       off_sw(4) = off
+      case ('lw_tauxar');   off_lw = off
+      case ('sw_status');   off_swst = off
+      case ('lw_status');   off_lwst = off
+      case ('swd_lev');     off_swdlev = off
+      case ('swd_col');     off_swdcol = off
+      case default
+        do m = 1, nmodes_clim
+          if (trim(name) == 'dgnumwet_'//trim(istr(m))) off_dgn(m) = off
+          if (trim(name) == 'qaerwat_'//trim(istr(m)))  off_qaw(m) = off
+          do l = 1, nspec_m(m)
+            if (trim(name) == 'specmmr_'//trim(istr(m))//'_'//trim(istr(l))) off_mmr(l, m) = off
+          end do
+        end do
+      end select
+    end do
+    if (min(off_t, off_pmid, off_pdeldry, off_troplev, off_lw, off_swst, off_lwst, off_swdlev, off_swdcol) < 0 .or. any(off_sw < 0) .or. &
+        any(off_dgn < 0) .or. any(off_qaw < 0)) call endrun('modal_aero_rank_init (colphys): the library does not offer every field this face moves')
+    do m = 1, nmodes_clim
+      if (any(off_mmr(:nspec_m(m), m) < 0)) call endrun('modal_aero_rank_init (colphys): a species record is missing')
+    end do
+    in_base = transfer(colphys_hostface_in_base(hf), in_base)
+    out_base = transfer(colphys_hostface_out_base(hf), out_base)
+  contains
+    function istr(n) result(t)
+      integer, intent(in) :: n
+      character(len=8) :: t
+      write(t, '(i0)') n
+    end function istr
+  end subroutine modal_aero_rank_init
+
+  subroutine modal_aero_rank_final()
+    integer(c_int) :: rc
+    if (c_associated(hf)) rc = colphys_hostface_destroy(hf)
+    hf = c_null_ptr
+    if (allocated(ncol_rank)) deallocate(ncol_rank)
+    if (allocated(off_dgn)) deallocate(off_dgn, off_qaw, off_mmr)
+    nchunks_rank = 0
+  end subroutine modal_aero_rank_final
+
+  function rec_in(off, c) result(addr)
+    integer(c_int64_t), intent(in) :: off
+    integer, intent(in) :: c
+    type(c_ptr) :: addr
+    addr = transfer(in_base + int(c - 1, c_intptr_t) * in_rec + off, addr)
+  end function rec_in
+  function rec_out(off, c) result(addr)
+    integer(c_int64_t), intent(in) :: off
+    integer, intent(in) :: c
+    type(c_ptr) :: addr
+    addr = transfer(out_base + int(c - 1, c_intptr_t) * out_rec + off, addr)
+  end function rec_out
+
+  ! chunk c's optics inputs into its record: the same accessor calls as marshal_inputs, whole (pcols,pver) arrays copied as
+  ! they are (padding columns travel and are never read on the device)
+  subroutine modal_aero_rank_push(c, state, pbuf)
+    use tropopause, only: tropopause_findChemTrop
+    integer, intent(in) :: c
+    type(physics_state), intent(in), target :: state
+    type(physics_buffer_desc), pointer :: pbuf(:)
+    real(r8), pointer :: p2(:,:), dgnumwet_m(:,:,:), qaerwat_m(:,:,:), mmr(:,:)
+    integer(c_int32_t), pointer :: pi(:)
+    integer(c_int32_t) :: troplevchem(pcols)
+    integer :: m, l
+    if (.not. c_associated(hf)) call endrun('modal_aero_rank_push (colphys): modal_aero_rank_init has not been called')
+    if (state%ncol /= ncol_rank(c)) call endrun('modal_aero_rank_push (colphys): state%ncol differs from the count given to modal_aero_rank_init')
+    call c_f_pointer(rec_in(off_pdeldry, c), p2, [pcols, pver]); p2 = state%pdeldry(:pcols, :pver)
+    call c_f_pointer(rec_in(off_pmid, c), p2, [pcols, pver]);    p2 = state%pmid(:pcols, :pver)
+    call c_f_pointer(rec_in(off_t, c), p2, [pcols, pver]);       p2 = state%t(:pcols, :pver)
+    call pbuf_get_field(pbuf, dgnumwet_idx, dgnumwet_m)                              ! :679-681 / :1320-1322
+    call pbuf_get_field(pbuf, qaerwat_idx,  qaerwat_m)
+    do m = 1, nmodes_clim
+      call c_f_pointer(rec_in(off_dgn(m), c), p2, [pcols, pver]); p2 = dgnumwet_m(:pcols, :pver, m)
+      call c_f_pointer(rec_in(off_qaw(m), c), p2, [pcols, pver]); p2 = qaerwat_m(:pcols, :pver, m)
+      do l = 1, nspec_m(m)
+        call rad_cnst_get_aer_mmr(0, m, l, 'a', state, pbuf, mmr)                   ! :759 / :1353
+        call c_f_pointer(rec_in(off_mmr(l, m), c), p2, [pcols, pver]); p2 = mmr(:pcols, :pver)
+      end do
+    end do
+    troplevchem = 1
+    call tropopause_findChemTrop(state, troplevchem)                                ! :679
+    call c_f_pointer(rec_in(off_troplev, c), pi, [pcols]); pi = troplevchem
+  end subroutine modal_aero_rank_push
+
+  subroutine modal_aero_rank_run()
+    if (.not. c_associated(hf)) call endrun('modal_aero_rank_run (colphys): modal_aero_rank_init has not been called')
+    if (colphys_hostface_run(hf, 0._c_double, COLPHYS_DYCORE_FV, 0._c_double) /= 0) call rank_fail('colphys_hostface_run')
+  end subroutine modal_aero_rank_run
+
+  ! chunk c's modal_aero_sw results: the four radiative arrays for 1:ncol, the sanity check of :997-1029, the history fields
+  subroutine modal_aero_rank_pull_sw(c, state, nnite, idxnite, tauxar, wa, ga, fa)
+    integer, intent(in) :: c
+    type(physics_state), intent(in) :: state
+    integer, intent(in) :: nnite
+    integer, intent(in) :: idxnite(nnite)
+    real(r8), intent(out) :: tauxar(pcols,0:pver,nswbands), wa(pcols,0:pver,nswbands), ga(pcols,0:pver,nswbands), fa(pcols,0:pver,nswbands)
+    real(r8), pointer :: p3(:,:,:), p2(:,:)
+    integer(c_int32_t), pointer :: st(:)
+    real(r8), allocatable :: dlev(:,:,:), dcol(:,:)
+    integer :: n
+    n = state%ncol
+    call c_f_pointer(rec_out(off_sw(1), c), p3, [pcols, pver + 1, nswbands]); tauxar(:n,:,:) = p3(:n,:,:)
+    call c_f_pointer(rec_out(off_sw(2), c), p3, [pcols, pver + 1, nswbands]); wa(:n,:,:) = p3(:n,:,:)
+    call c_f_pointer(rec_out(off_sw(3), c), p3, [pcols, pver + 1, nswbands]); ga(:n,:,:) = p3(:n,:,:)
+    call c_f_pointer(rec_out(off_sw(4), c), p3, [pcols, pver + 1, nswbands]); fa(:n,:,:) = p3(:n,:,:)
+    call c_f_pointer(rec_out(off_swst, c), st, [pcols])
+    call check_status('modal_aero_sw', state%lchnk, n, st, nerr_dopaer_sw, -1)
+    allocate(dlev(pcols,pver,nlevf), dcol(pcols,ncolf0+3*nmodes_clim))
+    call c_f_pointer(rec_out(off_swdlev, c), p3, [pcols, pver, nlevf]);       dlev = p3
+    call c_f_pointer(rec_out(off_swdcol, c), p2, [pcols, ncolf0+3*nmodes_clim]); dcol = p2
+    call sw_history_out(state%lchnk, n, nnite, idxnite, dlev, dcol)
+  end subroutine modal_aero_rank_pull_sw
+
+  subroutine modal_aero_rank_pull_lw(c, state, tauxar)
+    integer, intent(in) :: c
+    type(physics_state), intent(in) :: state
+    real(r8), intent(out) :: tauxar(pcols,pver,nlwbands)
+    real(r8), pointer :: p3(:,:,:)
+    integer(c_int32_t), pointer :: st(:)
+    integer :: n
+    n = state%ncol
+    call c_f_pointer(rec_out(off_lw, c), p3, [pcols, pver, nlwbands]); tauxar(:n,:,:) = p3(:n,:,:)
+    call c_f_pointer(rec_out(off_lwst, c), st, [pcols])
+    call check_status('modal_aero_lw', state%lchnk, n, st, nerr_dopaer_lw, nerrmax_dopaer)
+  end subroutine modal_aero_rank_pull_lw
 
 end module AER_MODULE

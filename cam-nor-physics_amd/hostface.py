@@ -114,9 +114,12 @@ class HostFace:
 
     # ---- filling from / comparing with the synthetic rank of cam_nor_physics_amd.synth ---------------------------------------
     def fill_from_synth(self, st, aer=None, props=None):
-        for k in ("t", "q", "u", "v", "pmid", "pdel", "rpdel", "lnpmid", "zm", "cld", "pint", "lnpint", "zi", "phis", "pblh", "tpert", "landfrac"):
-            self.put_columns(k, st[k])
-        self.put_columns("ps", st["pint"][:, -1])
+        if self.what & HF_ZM:
+            for k in ("t", "q", "u", "v", "pmid", "pdel", "rpdel", "lnpmid", "zm", "cld", "pint", "lnpint", "zi", "phis", "pblh", "tpert", "landfrac"):
+                self.put_columns(k, st[k])
+            self.put_columns("ps", st["pint"][:, -1])
+        else:                                               # the optics alone
+            self.put_columns("t", st["t"]); self.put_columns("pmid", st["pmid"])
         if self.what & HF_AERO:
             self.put_columns("pdeldry", st["pdeldry"])
             for m in range(len(props["nspec"])):

@@ -558,10 +558,12 @@ int colphys_zm_conv_tend_dev(int ncol, int pver, int pcols, double ztodt, int dy
  *                      swd_col (pcols, COLPHYS_SWD_NCOL + 3 nmodes)
  * mu ... ideep keep the reference's per-chunk gathered layout (slot j of the chunk in row j).
  * ------------------------------------------------------------------------------------------------- */
-#define COLPHYS_HF_ZM     1   /* zm_conv_tend (always on) */
-#define COLPHYS_HF_AERO   2   /* + modal_aero_sw, modal_aero_lw (colphys_aero_tables_set first) */
+#define COLPHYS_HF_ZM     1   /* zm_conv_tend */
+#define COLPHYS_HF_AERO   2   /* modal_aero_sw, modal_aero_lw (colphys_aero_tables_set first).  Without COLPHYS_HF_ZM the face moves the
+                               optics' fields only: inputs t pmid (read by the SW diagnostics) + the COLPHYS_HF_AERO inputs, no ZM outputs,
+                               no lengath -- the radiation driver's call, away from the convection step */
 #define COLPHYS_HF_SWDIAG 4   /* + modal_aero_sw's history diagnostics (needs COLPHYS_HF_AERO) */
-#define COLPHYS_HF_HIST   8   /* + zm_conv_tend's history / argument outputs (ABI 4) */
+#define COLPHYS_HF_HIST   8   /* + zm_conv_tend's history / argument outputs (ABI 4; needs COLPHYS_HF_ZM) */
 
 typedef struct colphys_hostface colphys_hostface;
 

@@ -191,6 +191,22 @@ class RefOracle:
                                         *[_d(o[k]) for k in ("lev", "col", "lev_f", "col_f")])
         return o
 
+    def modal_aero_rank(self, state, aer, nite=None):
+        """(shim library only) the optics' whole-rank dispatch, tests/fortran/hostface_aero_driver.F90: every chunk pushed, ONE
+        run, every chunk pulled; returns modal_aero_sw's and modal_aero_lw's outputs and what reached outfld, as the three
+        per-chunk methods above do"""
+        n, pver = state["t"].shape
+        nmodes, _, nsw, nlw = self.aero_dims
+        a, tl = self._aero_args(state, aer)
+        nt = np.zeros(n, dtype=np.int32) if nite is None else np.ascontiguousarray(nite, dtype=np.int32)
+        ncf = 23 + 3 * nmodes
+        o = {k: np.zeros((n, nsw, pver + 1)) for k in ("tauxar", "wa", "ga", "fa")}
+        o.update(lw_tauxar=np.zeros((n, nlw, pver)), lev=np.zeros((5, n, pver)), col=np.zeros((ncf, n)), lev_f=np.zeros((5, n, pver)),
+                 col_f=np.zeros((ncf, n)))
+        self.lib.hfa_modal_aero(C.c_int(n), *[_d(x) for x in a], _i(tl), _i(nt),
+                                *[_d(o[k]) for k in ("tauxar", "wa", "ga", "fa", "lw_tauxar", "lev", "col", "lev_f", "col_f")])
+        return o
+
     def modal_aero_lw(self, state, aer):
         n, pver = state["t"].shape
         nlw = self.aero_dims[3]

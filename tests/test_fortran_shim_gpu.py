@@ -99,6 +99,36 @@ def test_fortran_optics_caller_on_hip_engine_matches_reference_golden(name):
             assert_close(nm + tag, dg["col" + tag][i], g["swd_col" + tag][i])
 
 
+@pytest.mark.parametrize("name", cases.AERO_GOLDEN)
+def test_fortran_optics_whole_rank_dispatch_matches_reference_golden(name):
+    """The optics' half of the host face from Fortran (modal_aero_rank_* of the shim's `module modal_aer_opt`,
+    tests/fortran/hostface_aero_driver.F90): the chunks' fields fetched through the same accessors as the per-chunk calls and
+    pushed into the records, ONE dispatch for all chunks, results and history fields pulled per chunk -- against the goldens of
+    the reference's per-chunk modal_aero_sw / modal_aero_lw."""
+    g = cases.load_golden(name)
+    n, pver = g["in_t"].shape
+    f = shim(pver)
+    props = cases.aero_props_from_golden(g)
+    f.aero_tables_set(props, synth.PHYSCONST)
+    st = {k: g["in_" + k] for k in ("pdeldry", "pmid", "t")}
+    aer = {k: g["in_" + k] for k in ("specmmr", "dgnumwet", "qaerwat", "troplevchem")}
+    o = f.modal_aero_rank(st, aer, g["in_nite"])
+    for k in ("tauxar", "wa", "ga", "fa"):
+        assert_close("rank modal_aero_sw." + k, o[k], g["sw_" + k])
+    assert_close("rank modal_aero_lw.tauxar", o["lw_tauxar"], g["lw_tauxar"])
+    lev_names, col_names = cases.swd_field_names(len(props["nspec"]))
+    for tag in ("", "_f"):
+        for i, nm in enumerate(lev_names):
+            assert_close("rank " + nm + tag, o["lev" + tag][i], g["swd_lev" + tag][i])
+        for i, nm in enumerate(col_names):
+            assert_close("rank " + nm + tag, o["col" + tag][i], g["swd_col" + tag][i])
+    # and bit for bit what the per-chunk calls of the same shim return (same kernels, other route)
+    sw = f.modal_aero_sw(st, aer)
+    for k in ("tauxar", "wa", "ga", "fa"):
+        assert np.array_equal(o[k], sw[k]), k
+    assert np.array_equal(o["lw_tauxar"], f.modal_aero_lw(st, aer)["tauxar"])
+
+
 _HALT_SCRIPT = r"""
 import os, sys
 import numpy as np

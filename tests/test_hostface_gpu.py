@@ -43,7 +43,15 @@ def active_rows(ncols, pcols):
     return np.concatenate([c * pcols + np.arange(n) for c, n in enumerate(ncols)])
 
 
-def compare(hf, r, ncols, pcols, pver, with_aero, sw_diag, hist, same_chunking):
+def compare(hf, r, ncols, pcols, pver, with_aero, sw_diag, hist, same_chunking, with_zm=True):
+    ncol = int(np.sum(ncols))
+    if with_zm:
+        compare_zm(hf, r, ncols, pcols, pver, hist, same_chunking)
+    if with_aero:
+        compare_optics(hf, r, ncol, pver, sw_diag)
+
+
+def compare_zm(hf, r, ncols, pcols, pver, hist, same_chunking):
     ncol = int(np.sum(ncols))
     for k in ZM_COL + ZM_MID + ZM_INT:
         assert np.array_equal(hf.get_columns(k), r[k]), k
@@ -77,31 +85,36 @@ def compare(hf, r, ncols, pcols, pver, with_aero, sw_diag, hist, same_chunking):
     assert np.array_equal(jt[g_rows], r["jctop"][col_of_row[src]].astype(np.int32))
     assert np.array_equal(maxg[g_rows], r["jcbot"][col_of_row[src]].astype(np.int32))
     assert np.array_equal(mu[g_rows] * 100.0 / synth.PHYSCONST["gravit"], r["mu_out"][col_of_row[src]])
-    if with_aero:
-        nsw, nlw = synth.NSWBANDS, synth.NLWBANDS
-        for k in ("tauxar", "wa", "ga", "fa"):
-            got = hf.get_columns("sw_" + k).reshape(ncol, nsw, pver + 1)          # (pcols, 0:pver, band): level fastest, then band
-            assert np.array_equal(got, r["sw_" + k]), k
-        assert np.array_equal(hf.get_columns("lw_tauxar").reshape(ncol, nlw, pver), r["lw_tauxar"])
-        assert np.array_equal(hf.get_columns("sw_status"), r["sw_status"]) and np.array_equal(hf.get_columns("lw_status"), r["lw_status"])
-        if sw_diag:
-            lev = hf.get_columns("swd_lev").reshape(ncol, abi.SWD_NLEV, pver).transpose(1, 0, 2)
-            col = hf.get_columns("swd_col").T
-            assert np.array_equal(lev, r["swd_lev"]) and np.array_equal(col, r["swd_col"])
 
 
-@pytest.mark.parametrize("pver,ncols,what,nslices", [
-    (32, [16, 16, 9, 16, 1, 16, 16, 3], HF_ZM | HF_AERO | HF_SWDIAG | HF_HIST, 3),       # ragged chunks anywhere, three slices
-    (32, [16] * 20 + [7], HF_ZM, 1),                                                       # ZM only, one slice
-    (70, [16] * 9 + [12], HF_ZM | HF_AERO, 2),                                             # L70: wide optics records (14 x 71 levels) in pieces
-    (26, [5], HF_ZM | HF_AERO | HF_SWDIAG, 0),                                             # one small chunk
+def compare_optics(hf, r, ncol, pver, sw_diag):
+    nsw, nlw = synth.NSWBANDS, synth.NLWBANDS
+    for k in ("tauxar", "wa", "ga", "fa"):
+        got = hf.get_columns("sw_" + k).reshape(ncol, nsw, pver + 1)              # (pcols, 0:pver, band): level fastest, then band
+        assert np.array_equal(got, r["sw_" + k]), k
+    assert np.array_equal(hf.get_columns("lw_tauxar").reshape(ncol, nlw, pver), r["lw_tauxar"])
+    assert np.array_equal(hf.get_columns("sw_status"), r["sw_status"]) and np.array_equal(hf.get_columns("lw_status"), r["lw_status"])
+    if sw_diag:
+        lev = hf.get_columns("swd_lev").reshape(ncol, abi.SWD_NLEV, pver).transpose(1, 0, 2)
+        col = hf.get_columns("swd_col").T
+        assert np.array_equal(lev, r["swd_lev"]) and np.array_equal(col, r["swd_col"])
+
+
+@pytest.mark.parametrize("pver,ncols,what,nslices,pcols", [
+    (32, [16, 16, 9, 16, 1, 16, 16, 3], HF_ZM | HF_AERO | HF_SWDIAG | HF_HIST, 3, 16),   # ragged chunks anywhere, three slices
+    (32, [16] * 20 + [7], HF_ZM, 1, 16),                                                   # ZM only, one slice
+    (70, [16] * 9 + [12], HF_ZM | HF_AERO, 2, 16),                                         # L70: wide optics records (14 x 71 levels) in pieces
+    (26, [5], HF_ZM | HF_AERO | HF_SWDIAG, 0, 16),                                         # one small chunk
+    (32, [48, 33, 48, 48, 17], HF_ZM | HF_AERO | HF_SWDIAG | HF_HIST, 2, 48),             # chunks wider than a re-layout block (two column blocks)
+    (32, [8] * 30 + [3], HF_ZM | HF_AERO, 4, 8),                                           # narrow chunks
+    (32, [16] * 11 + [5], HF_AERO | HF_SWDIAG, 3, 16),                                     # the optics alone (the radiation driver's call)
+    (70, [16, 2], HF_AERO, 0, 16),
 ])
-def test_hostface_matches_resident_path(pver, ncols, what, nslices):
-    pcols = 16
+def test_hostface_matches_resident_path(pver, ncols, what, nslices, pcols):
     ncols = np.array(ncols, np.int32)
     ncol = int(ncols.sum())
     eng = engine(cases.default_params(pver))
-    with_aero, sw_diag, hist = bool(what & HF_AERO), bool(what & HF_SWDIAG), bool(what & HF_HIST)
+    with_zm, with_aero, sw_diag, hist = bool(what & HF_ZM), bool(what & HF_AERO), bool(what & HF_SWDIAG), bool(what & HF_HIST)
     props = synth.make_aero_props(3)
     st = synth.make_state(ncol, pver, 1212, moist_boost=1.15)
     aer = synth.make_aero_state(ncol, pver, props, 3) if with_aero else None
@@ -114,9 +127,11 @@ def test_hostface_matches_resident_path(pver, ncols, what, nslices):
         t = hf.run(synth.ZTODT)
         assert t["wall_ms"] > 0 and t["h2d_bytes"] == len(ncols) * hf.in_rec and t["d2h_bytes"] == len(ncols) * hf.out_rec
         same = bool((ncols[:-1] == pcols).all())
-        compare(hf, r, ncols, pcols, pver, with_aero, sw_diag, hist, same)
+        compare(hf, r, ncols, pcols, pver, with_aero, sw_diag, hist, same, with_zm)
+        if not with_zm:
+            assert "lengath" not in hf.fields and "ptend_s" not in hf.fields and "q" not in hf.fields
         # a second run on the same records gives the same bits (no state is kept between runs)
-        first = {k: hf.view(k).copy() for k in ("ptend_s", "mu", "ideep", "lengath")}
+        first = {k: hf.view(k).copy() for k in (("ptend_s", "mu", "ideep", "lengath") if with_zm else ("sw_tauxar", "lw_tauxar"))}
         hf.run(synth.ZTODT)
         for k, v in first.items():
             assert np.array_equal(hf.view(k), v), k
@@ -124,6 +139,15 @@ def test_hostface_matches_resident_path(pver, ncols, what, nslices):
         hf.close()
     if pver >= 26 and ncol > 100:
         assert r["lengath"].sum() > 0
+
+
+def test_hostface_argument_errors():
+    eng = engine(cases.default_params(32))
+    eng.aero_tables_set(synth.make_aero_props(3), synth.PHYSCONST)
+    ncols = np.array([16, 4], np.int32)
+    for what in (0, HF_SWDIAG, HF_HIST | HF_AERO, HF_SWDIAG | HF_ZM):
+        with pytest.raises(RuntimeError):
+            HostFace(eng, ncols, 16, 32, what)
 
 
 def test_hostface_ne30_rank_matches_resident_path_and_reports_its_times():
