@@ -73,7 +73,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "cam-nor-physics_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h", ".inc")):
             with open(os.path.join(d, f), "rb") as fh:
                 h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
