@@ -708,7 +708,13 @@ __global__ __launch_bounds__(WAVE) void zm_trigger_fused_kernel(ZmDev P, int nco
 #define SYNC() wave_sync()
 #endif
 
-constexpr int PLUME_NARR = 49;
+// cldprp's work profiles: 49 names on 36 LDS slots (round 3: the waves resident per CU are set by this footprint -- 11 at L32
+// with 49 slots, 15 with 36 -- and the plume kernels' time at scale by the waves resident).  cldprp runs in three phases --
+// entrainment (k1 .. i4, f, eps, gamma, mcp, mrl, hsat, z: last read at :3598), updraft thermodynamics, downdraft (md, ed, sd, qd,
+// mc, evp, cmeg, hd, td, qds, pflx: first touched at :3880) -- and a downdraft profile takes the slot of an entrainment profile;
+// its initial value (:3245-3314) is set when the downdraft phase begins instead of at the top, to the same bits.  tp / qstp
+// (closure only) take the slots of tu / hu (updraft phase only) and are loaded after cldprp.
+constexpr int PLUME_NARR = 36;
 #ifndef SERIAL_UNROLL
 #define SERIAL_UNROLL 4                    // serial level loops of the plume kernels: four iterations of LDS reads in flight (plume2 0.21 -> 0.19 ms)
 #endif
@@ -720,11 +726,15 @@ struct PlumeLds {
         *hsat;
     __device__ void carve(double *base, int LD)
     {
-        double **slots[] = {&q, &t, &p, &z, &s, &zf, &shat, &qhat, &dp, &tp, &qstp, &mu, &eu, &du, &md, &ed, &sd, &qd, &mc, &qu,
-                            &su, &qst, &ql, &cmeg, &pflx, &evp, &cu, &rprd, &qcde, &gamma, &dz, &hu, &hd, &eps, &f, &k1, &i2, &i3,
-                            &i4, &qsthat, &hsthat, &gamhat, &qds, &mcp, &mrl, &tu, &td, &hmn, &hsat};
+        double **slots[] = {&q, &t, &p, &z, &s, &zf, &shat, &qhat, &dp, &mu, &eu, &du, &qu, &su, &qst, &ql, &cu, &rprd, &qcde,
+                            &gamma, &dz, &hu, &eps, &f, &k1, &i2, &i3, &i4, &qsthat, &hsthat, &gamhat, &mcp, &mrl, &tu, &hmn, &hsat};
+        static_assert(sizeof(slots) / sizeof(slots[0]) == PLUME_NARR, "PLUME_NARR");
         int n = 0;
         for (double **sl : slots) { *sl = base + (size_t)n * LD; ++n; }
+        // downdraft phase over entrainment phase
+        md = k1; ed = i2; sd = i3; qd = i4; mc = f; evp = eps; cmeg = gamma; hd = mcp; td = mrl; qds = hsat; pflx = z;
+        // closure over updraft phase
+        tp = tu; qstp = hu;
     }
 };
 
@@ -779,8 +789,7 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
         A.dz[k] = A.zf[k] - A.zf[k + 1];
         A.k1[k] = 0.0; A.i2[k] = 0.0; A.i3[k] = 0.0; A.i4[k] = 0.0;
         A.mu[k] = 0.0; A.f[k] = 0.0; A.eps[k] = 0.0; A.eu[k] = 0.0; A.du[k] = 0.0; A.ql[k] = 0.0; A.cu[k] = 0.0;
-        A.evp[k] = 0.0; A.cmeg[k] = 0.0; A.qds[k] = qk; A.md[k] = 0.0; A.ed[k] = 0.0; A.sd[k] = sk;
-        A.qd[k] = qk; A.mc[k] = 0.0; A.qu[k] = qk; A.su[k] = sk;
+        A.qu[k] = qk; A.su[k] = sk;          // (evp cmeg qds md ed sd qd mc hd td: set where the downdraft phase begins, see PlumeLds)
         double est, qst;
         qsat_hPa(P, tk, pk, est, qst);
         if (pk - est <= 0.0) qst = 1.0;
@@ -794,10 +803,8 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
         A.hmn[k] = hmn;
         A.hsat[k] = mcp * tk + grav * A.z[k] + mrl * qst;
         A.hu[k] = hmn;
-        A.hd[k] = hmn;
         A.rprd[k] = 0.0;
         A.qcde[k] = 0.0;
-        A.td[k] = (hmn - grav * A.zf[k] - (1.0 + dcol * tmelt) * rl * qk) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * qk));
         A.tu[k] = 0.0;
     }
     SYNC();
@@ -1076,7 +1083,17 @@ __device__ void cldprp_w(const ZmDev &P, int pver, int msg, const PlumeLds &A, i
         qc = wrote;
     }
 
-    // downdraft :3880-3975
+    // downdraft :3880-3975.  Its profiles take the LDS slots of the entrainment phase's (PlumeLds): their initial values of
+    // :3245-3314, which that loop no longer sets, are set here -- same expressions, same operands (hmn as stored)
+    SYNC();
+    PAR(k, 1, pver) {
+        const double qk = A.q[k], hmn = A.hmn[k];
+        A.evp[k] = 0.0; A.cmeg[k] = 0.0; A.qds[k] = qk; A.md[k] = 0.0; A.ed[k] = 0.0; A.sd[k] = A.s[k];
+        A.qd[k] = qk; A.mc[k] = 0.0;
+        A.hd[k] = hmn;
+        A.td[k] = (hmn - grav * A.zf[k] - (1.0 + dcol * tmelt) * rl * qk) / (cp * (1.0 + (cpvir - dcol * (rl / cp)) * qk));
+    }
+    SYNC();
     const double alfa = P.alfadet;
     o.jt = min(o.jt, jb - 1);
     o.jd = max(o.j0, o.jt + 1);
@@ -1371,7 +1388,6 @@ __global__ __launch_bounds__(WAVE, CHAIN_WAVES_PER_SIMD) void zm_plume2_kernel(Z
     }
     const ColIn c = make_colin(P, io, col, pver);
     plume_load<PSTEP>(P, c, A, lane);
-    PAR(k, 1, pver) { A.tp[k] = ws.tp2[col * L + k - 1]; A.qstp[k] = ws.qstp2[col * L + k - 1]; }
 
     const int maxg = ws.mx2[col], lelg = ws.lel2[col], lcl = ws.lcl2[col];                   // :1156-1174
     const double cape = ws.cape2[col], tl = ws.tl2[col], dmpdz = ws.dmpdz2[col];
@@ -1383,6 +1399,8 @@ __global__ __launch_bounds__(WAVE, CHAIN_WAVES_PER_SIMD) void zm_plume2_kernel(Z
     PlumeIdx ix;
     cldprp_w<false, PSTEP>(P, pver, msg, A, maxg, lelg, c.landfrac, lane, ix);               // :1216
     const int jt = ix.jt, mx = maxg;
+    // the second ascent's parcel profiles, for the closure: into the slots cldprp's updraft phase has left (PlumeLds)
+    PAR(k, 1, pver) { A.tp[k] = ws.tp2[col * L + k - 1]; A.qstp[k] = ws.qstp2[col * L + k - 1]; }
 
     PAR(k, msg + 1, pver) {                                                                  // :1252-1262
         const double dzk = (A.zf[k] - A.zf[k + 1]), dpk = A.dp[k];
@@ -1631,7 +1649,23 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     int cpwv = (pver <= WAVE / 2 && ncol >= 150000) ? 2 : 1;
     if (const char *e = getenv("COLPHYS_PLUME_CPW")) cpwv = (atoi(e) == 2 && pver <= WAVE / 2) ? 2 : 1;
     const size_t lds_w = (size_t)cpwv * (PLUME_NARR + 2) * (pver + 2) * sizeof(double);
-    const int nper = ncol < 256 * 12 ? ncol : 256 * 12;       // persistent: ~12 waves per CU fit in LDS at L32
+    // Persistent waves over the device-side list: a multiple of what is RESIDENT at once (LDS: 11 waves per CU at L32, 5 with two
+    // columns per wave or at L70).  Round 3: the grid used to be 12 waves per CU whatever fitted; the waves beyond the resident
+    // set then ran as a second, nearly empty round -- ne120 plume2 5.83 ms with 12 per CU, 7.3 with 6, 5.15-5.28 with 5 or 10;
+    // 48 602 columns 0.333 -> 0.295 ms.  Twice the resident set: finer grain beside the optics' blocks (substep 2.705 -> 2.68 ms).
+    static int occ_cache[2][COLPHYS_MAX_PVER + 1] = {};
+    int &occ = occ_cache[cpwv - 1][pver];
+    if (occ == 0) {
+        int nb = 0;
+        const void *fn = cpwv == 2 ? (const void *)zm_plume2_kernel<2> : (const void *)zm_plume2_kernel<1>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WAVE, lds_w) != hipSuccess || nb < 1) nb = 6;
+        occ = nb;
+        if (getenv("COLPHYS_DEBUG_OCC")) fprintf(stderr, "plume kernels: %d resident waves per CU (cpw %d, pver %d, %zu B of LDS each)\n", nb, cpwv, pver, lds_w);
+    }
+    int wpc = 2 * occ;
+    if (const char *e = getenv("COLPHYS_PLUME_WPC")) wpc = atoi(e) > 0 ? atoi(e) : wpc;      // tests / A-B
+    const int n_cu = n_simd / 4;
+    const int nper = ncol < n_cu * wpc ? ncol : n_cu * wpc;
     if (cpwv == 2) hipLaunchKernelGGL(zm_plume1_kernel<2>, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, io, ws);
     else hipLaunchKernelGGL(zm_plume1_kernel<1>, dim3(nper), dim3(WAVE), lds_w, st, P, ncol, pver, io, ws);
     if (ev) { hipEventRecord(ev[3], st); hipEventRecord(ev[4], st); }
