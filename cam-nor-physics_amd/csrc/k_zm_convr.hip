@@ -687,14 +687,14 @@ __global__ __launch_bounds__(WAVE) void zm_trigger_fused_kernel(ZmDev P, int nco
 //
 // Only the triggered columns (~10 %) get here, so a lane-per-column mapping leaves the machine almost empty
 // (80 waves) and each lane drags ~50 private work profiles through scratch.  Instead every triggered column
-// gets its own wave, the work profiles live in LDS (49 x (pver+2) doubles = 13 KB at L32), and
+// gets its own wave, the work profiles live in LDS (49 names on 36 slots of pver+2 doubles: 10 KB at L32, see PlumeLds), and
 //   * loops that are element-wise in k run one level per lane            (PAR),
 //   * the genuine recurrences / searches / running sums run in the reference's order, redundantly on all
 //     lanes (uniform control flow: in SIMT that costs exactly what one lane would), reading and writing LDS.
 // A barrier separates a PAR phase from whatever reads its neighbours' levels.  Same arithmetic, same order.
-// PSTEP = lanes per column: 64, or 32 when pver <= 32 -- then a wave carries TWO columns, lanes 0..31 the first and 32..63
-// the second, each half with its own LDS profiles (otherwise half the lanes of every PAR loop idle and twice the waves run
-// the serial loops).  Nothing else changes: a lane belongs to a column and does what that column's control flow says; where
+// PSTEP = lanes per column: 64, or 32 in the two-columns-per-wave mode (pver <= 32; not selected by default any more, see
+// launch_zm_convr) -- then a wave carries TWO columns, lanes 0..31 the first and 32..63 the second, each half with its own LDS
+// profiles (otherwise half the lanes of every PAR loop idle and twice the waves run the serial loops).  Nothing else changes: a lane belongs to a column and does what that column's control flow says; where
 // the two columns of a wave disagree (loop bounds, `eps0 > 0`, the break of :3690) the wave runs both sides under EXEC
 // masks.  A block is one wave, so SYNC() inside such a branch is safe: LDS operations of a wave complete in order.
 // ------------------------------------------------------------------------------------------------------
@@ -1361,7 +1361,10 @@ __global__ __launch_bounds__(2 * WAVE, CHAIN_WAVES_PER_SIMD) void zm_ascent2_ker
 // Kernel 2c: second ensemble pass, closure, tendencies, precipitation integrals of the re-triggered columns
 // ------------------------------------------------------------------------------------------------------
 template <int CPWV>
-__global__ __launch_bounds__(WAVE, CHAIN_WAVES_PER_SIMD) void zm_plume2_kernel(ZmDev P, int ncol, int pver, double delt, colphys_zm_convr_io io,
+#ifndef PLUME_WAVES_PER_SIMD
+#define PLUME_WAVES_PER_SIMD CHAIN_WAVES_PER_SIMD
+#endif
+__global__ __launch_bounds__(WAVE, PLUME_WAVES_PER_SIMD) void zm_plume2_kernel(ZmDev P, int ncol, int pver, double delt, colphys_zm_convr_io io,
                                                         ZmWorkspace ws)
 {
     constexpr int PSTEP = WAVE / CPWV;          // lanes per column
@@ -1641,12 +1644,11 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
         hipLaunchKernelGGL(zm_trigger_fused_kernel, dim3(nblk), dim3(WAVE), lds, st, P, ncol, pver, io, ws);
     }
     if (ev) { hipEventRecord(ev[1], st); hipEventRecord(ev[2], st); }
-    // plume kernels: two columns per wave when a column's levels fit half a wave AND the listed columns outnumber the
-    // persistent waves several times over.  A pair of columns takes as long as its slower member plus what the two
-    // disagree on, so it pays only as throughput: 777 602 columns 16.75 -> 16.03 ms (plume2 3.59 -> 3.23), 48 602 columns
-    // -- one or two columns per wave anyway, the time is one column's serial chain -- 2.31 -> 2.37 ms per substep.
-    // (COLPHYS_PLUME_CPW=1|2: tests / A-B)
-    int cpwv = (pver <= WAVE / 2 && ncol >= 150000) ? 2 : 1;
+    // plume kernels: one column per wave.  Two columns per wave (pver <= 32; COLPHYS_PLUME_CPW=2, kept for tests / A-B) paid
+    // as throughput at ne120 while a wave's 49-profile footprint allowed 11 waves per CU (16.75 -> 16.03 ms in round 2); with
+    // the profiles on 36 slots 12 single-column waves are resident (the VGPR budget's limit), 7 pairs, and a pair still takes as
+    // long as its slower member plus what the two disagree on: ne120 plume2 3.71 ms single, 4.14 paired; 48 602 columns 0.28 / 0.32.
+    int cpwv = 1;
     if (const char *e = getenv("COLPHYS_PLUME_CPW")) cpwv = (atoi(e) == 2 && pver <= WAVE / 2) ? 2 : 1;
     const size_t lds_w = (size_t)cpwv * (PLUME_NARR + 2) * (pver + 2) * sizeof(double);
     // Persistent waves over the device-side list: a multiple of what is RESIDENT at once (LDS: 11 waves per CU at L32, 5 with two

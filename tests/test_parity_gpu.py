@@ -66,7 +66,7 @@ def check_zm(o, ref, ncol, pcols=cases.PCOLS):
 def test_zm_convr_vs_reference_golden(name, trig_mode, monkeypatch):
     """both mappings of the first ascent: wave pairs (what these column counts select) and the single-wave kernel
     that takes over when the column groups fill the SIMDs (forced here through COLPHYS_TRIG_MODE); and the plume kernels with
-    two columns per wave, which large column counts at up to 32 levels select (forced through COLPHYS_PLUME_CPW; L70 keeps
+    two columns per wave, the plume kernels' other mapping at up to 32 levels (forced through COLPHYS_PLUME_CPW; L70 keeps
     one column per wave whatever the setting)"""
     if trig_mode == "one-lane":                       # the wave-pair trigger with one lane per column (what > 16 384 columns select;
         monkeypatch.setenv("COLPHYS_LPC_TRIG", "1")   # these column counts take four lanes per column by themselves: "auto")
