@@ -6,6 +6,9 @@
 # variant: what the ISA scanner finds in it.  The two columns agree exactly when the scanner finds nothing: the differences are a
 # backend miscompile (a live-range-split copy ahead of a loop-exit block's EXEC restore), not an LDS ordering problem, and the
 # kind of barrier plays no part.
+# NOTE: the variants miscompile at commit e8b916b (where profiles/r03_plume_hazard.txt was taken).  The later re-packing of the
+# plume kernels' LDS profiles changed the register allocation and none of them trips the backend any more (the scanner reports
+# 0 hits for all of them, and all agree); to reproduce, take cam-nor-physics_amd/csrc/k_zm_convr.hip from that commit.
 # usage (GPU box): [HAZARD_VARIANTS="reg_wave lds_wave ..."] bash scripts/plume_hazard.sh
 set -e
 mkdir -p gpurun_out/hazard && rm -f gpurun_out/hazard/result.txt /tmp/hazard_base.npz
