@@ -1627,6 +1627,12 @@ int launch_zm_convr(const ZmDev &P, int ncol, int pver, int pcols, double delt, 
     if (lpc_asc_env == 1 || lpc_asc_env == 2 || lpc_asc_env == 4) lpc_asc = lpc_asc_env;
     int groups = TRIG_GROUPS_MAX;
     if (lpc_trig >= 2) groups = 2;              // blocks of two pairs: three of them share a CU at three waves per SIMD
+    // one lane per column and at most 1 024 waves (16 385 .. 32 768 columns): blocks of two pairs [A0 A1 B0 B1] put every wave on
+    // a SIMD of its own (a block's waves go round the four SIMDs) instead of pairing A and B on one -- the pairing is for the
+    // sizes where two waves per SIMD are unavoidable.  Trigger 0.59 -> 0.49 ms at 18 000 / 24 301 columns (substep 1.40 -> 1.27,
+    // 1.555 -> 1.54 ms), 1.99 -> 1.87 ms at 32 768; beyond, two-pair blocks lose (40 000 columns: 2.25 -> 2.40 ms).
+    else if (2 * nblk <= n_simd) groups = 2;
+    if (const char *e = getenv("COLPHYS_TRIG_GROUPS")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4) groups = g; }   // tests / A-B
     while (groups > 1 && lds2 * groups > 158 * 1024) groups /= 2;
     if (lds2 * groups > 160 * 1024) paired = false;
     if (paired) {

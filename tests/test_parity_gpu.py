@@ -1281,3 +1281,27 @@ def test_lane_quads_pairs_and_single_lanes_give_the_same_bits(monkeypatch):
     for lpc in ("2", "4"):
         for k, v in outs["1"].items():
             assert np.array_equal(outs[lpc][k], v), (lpc, k)
+
+
+def test_trigger_block_shapes_give_the_same_bits(monkeypatch):
+    """the trigger's blocks of one, two or four wave pairs (launch_zm_convr picks by column count: which waves share a SIMD)
+    are a placement matter only; a mid-size share, where the choice changed in round 3, against the C oracle on a sample"""
+    pver, ncol = 32, 24301
+    eng = engine(cases.default_params(pver))
+    st = synth.make_state(ncol, pver, 515, moist_boost=1.1)
+    args = cases.zm_args_from_state(st, st["zi"], st["zm"])
+    outs = {}
+    for g in ("1", "2", "4"):
+        monkeypatch.setenv("COLPHYS_TRIG_GROUPS", g)
+        outs[g] = run_zm(eng, args)
+    monkeypatch.delenv("COLPHYS_TRIG_GROUPS")
+    outs["default"] = run_zm(eng, args)
+    for g in ("1", "2", "default"):
+        for k, v in outs["4"].items():
+            assert np.array_equal(outs[g][k], v), (g, k)
+    n = 1600                                    # whole chunks
+    from c_oracle import COracle
+    ref = COracle(cases.default_params(pver)).zm_convr(*[a[:n] if hasattr(a, "shape") and a.shape[:1] == (ncol,) else a for a in args])
+    for k in ("heat", "qtnd", "prec", "cape"):
+        assert_close("zm_convr." + k, outs["default"][k][:n], ref[k][:n])
+    assert np.array_equal(outs["default"]["lengath"][:n // cases.PCOLS], ref["lengath"])
