@@ -26,6 +26,8 @@ bool g_init = false;
 int g_device = -1;
 ZmDev g_P;
 double *g_estbl = nullptr;          // device, [PLENEST+1], 1-based
+double *g_rz = nullptr;             // device, {rair, zvir}: what rairv / zvirv hold everywhere without WACCM-X (a caller that passes
+                                    // NULL for both fields of geopotential_t / zm_conv_tend gets these; colphys.h)
 AeroDev g_A;
 bool g_aero_set = false;
 std::vector<void *> g_aero_bufs;
@@ -245,6 +247,11 @@ int colphys_init(int device, const colphys_zm_params *p)
     for (int i = 1; i <= COLPHYS_PLENEST; ++i) tbl[i] = h_svp_trans(COLPHYS_TMIN_TBL + (double)(i - 1), p->tmelt);
     if (!g_estbl) HIPCHK(hipMalloc((void **)&g_estbl, sizeof(double) * (COLPHYS_PLENEST + 1)));
     HIPCHK(hipMemcpy(g_estbl, tbl.data(), sizeof(double) * (COLPHYS_PLENEST + 1), hipMemcpyHostToDevice));
+    {
+        const double rz[2] = {p->rair, p->zvir};
+        if (!g_rz) HIPCHK(hipMalloc((void **)&g_rz, sizeof(rz)));
+        HIPCHK(hipMemcpy(g_rz, rz, sizeof(rz), hipMemcpyHostToDevice));
+    }
     g_pin_arena.host = true;
     g_init = true;
     return COLPHYS_OK;
@@ -261,6 +268,8 @@ int colphys_finalize(void)
         g_evpool.clear();
         if (g_estbl) hipFree(g_estbl);
         g_estbl = nullptr;
+        if (g_rz) hipFree(g_rz);
+        g_rz = nullptr;
         for (void *b : g_aero_bufs) hipFree(b);
         g_aero_bufs.clear();
         g_aero_set = false;
@@ -303,12 +312,14 @@ int colphys_geopotential_t_dev(int ncol, int pver, int dycore_kind, int nq, int 
     if ((rc = check_ready()) || (rc = check_dims(ncol, pver))) return rc;
     if (dycore_kind < 0 || dycore_kind > 2) return fail(COLPHYS_ERR_ARG, "bad dycore_kind");
     if (nq < 1 || nspecies < 1 || nspecies > nq) return fail(COLPHYS_ERR_ARG, "need 1 <= nspecies <= nq");
-    if (!t || !q || !rair || !zvir || !zi || !zm) return fail(COLPHYS_ERR_ARG, "null pointer");
+    if (!t || !q || !zi || !zm) return fail(COLPHYS_ERR_ARG, "null pointer");
+    if ((rair == nullptr) != (zvir == nullptr)) return fail(COLPHYS_ERR_ARG, "rair and zvir: both fields, or both NULL (the engine's constants)");
     if (dycore_kind == COLPHYS_DYCORE_FV ? (!piln || !pint || !rpdel) : (!pdel || !pmid))
         return fail(COLPHYS_ERR_ARG, "null pressure field for this dycore_kind");
     ProfScope ps(COLPHYS_K_GEOPOTENTIAL, (hipStream_t)stream);
-    rc = launch_geopotential_t(ncol, pver, dycore_kind, nq, nspecies, piln, pint, pmid, pdel, rpdel, t, q, rair, gravit,
-                               zvir, zi, zm, (hipStream_t)stream);
+    const int uni = rair == nullptr;
+    rc = launch_geopotential_t(ncol, pver, dycore_kind, nq, nspecies, piln, pint, pmid, pdel, rpdel, t, q, uni ? g_rz : rair, gravit,
+                               uni ? g_rz + 1 : zvir, zi, zm, (hipStream_t)stream, uni);
     return rc ? fail(rc, "geopotential_t launch failed") : COLPHYS_OK;
 }
 
@@ -539,13 +550,15 @@ static int zm_conv_tend_impl(int ncol, int pver, int pcols, double ztodt, int dy
     if (pcols < 1 || pcols > 1024) return fail(COLPHYS_ERR_ARG, "pcols must be in 1..1024");
     {
         const void *need[] = {io->t, io->q, io->u, io->v, io->pmid, io->pint, io->pdel, io->rpdel, io->lnpint, io->lnpmid, io->zm,
-                              io->zi, io->phis, io->ps, io->rair, io->zvir, io->pblh, io->tpert, io->landfrac, io->cld,
+                              io->zi, io->phis, io->ps, io->pblh, io->tpert, io->landfrac, io->cld,
                               io->ptend_s, io->ptend_q, io->ptend_u, io->ptend_v, io->prec, io->snow, io->rliq, io->rice,
                               io->jctop, io->jcbot, io->cape, io->ql, io->rprd, io->evapcdp, io->dlf, io->mconzm, io->flxprec,
                               io->flxsnow, io->mu, io->md, io->du, io->eu, io->ed, io->dp, io->dsubcld, io->jt, io->maxg,
                               io->ideep, io->lengath, io->status};
         for (const void *p : need)
             if (!p) return fail(COLPHYS_ERR_ARG, "null pointer in colphys_zm_conv_tend_io");
+        if ((io->rair == nullptr) != (io->zvir == nullptr))
+            return fail(COLPHYS_ERR_ARG, "colphys_zm_conv_tend_io: rair and zvir are both fields, or both NULL (the engine's constants)");
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t nM = (size_t)ncol * pver, nI = (size_t)ncol * (pver + 1);
@@ -621,7 +634,9 @@ static int zm_conv_tend_impl(int ncol, int pver, int pcols, double ztodt, int dy
         double *t2 = w.take<double>(nM), *zi_s = w.take<double>(nI), *zm_s = w.take<double>(nM);
         ZmTailSmall T{};
         T.ncol = ncol; T.pver = pver; T.pcols = pcols; T.dycore_kind = dycore_kind; T.ztodt = ztodt; T.qmin = qmin;
-        T.lnpint = io->lnpint; T.pint = io->pint; T.pmid = io->pmid; T.pdel = io->pdel; T.rpdel = io->rpdel; T.rair = io->rair; T.zvir = io->zvir;
+        T.lnpint = io->lnpint; T.pint = io->pint; T.pmid = io->pmid; T.pdel = io->pdel; T.rpdel = io->rpdel;
+        T.rz_uniform = io->rair == nullptr;
+        T.rair = T.rz_uniform ? g_rz : io->rair; T.zvir = T.rz_uniform ? g_rz + 1 : io->zvir;
         T.t1 = t1; T.q1 = q1; T.u1 = u1; T.v1 = v1; T.zi1 = zi1; T.zm1 = zm1; T.t2 = t2; T.zi_scratch = zi_s; T.zm_scratch = zm_s;
         T.u = io->u; T.v = io->v; T.evap = e; T.mom = m;
         T.ptend_s = io->ptend_s; T.ptend_q = io->ptend_q; T.ptend_u = io->ptend_u; T.ptend_v = io->ptend_v;

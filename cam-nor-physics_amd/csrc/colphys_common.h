@@ -328,7 +328,7 @@ __device__ inline double svp_water_gg(double t)
 int launch_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspecies, const double *piln,
                           const double *pint, const double *pmid, const double *pdel, const double *rpdel,
                           const double *t, const double *q, const double *rair, double gravit, const double *zvir,
-                          double *zi, double *zm, hipStream_t st);
+                          double *zi, double *zm, hipStream_t st, int rz_uniform = 0);
 
 int launch_geopotential_dse(int ncol, int pver, int dycore_kind, int nspecies, const double *piln, const double *pint,
                             const double *pmid, const double *pdel, const double *rpdel, const double *dse, const double *q,
@@ -374,6 +374,7 @@ int launch_momtran(const ZmDev &P, int ncol, int pver, int pcols, double dt, con
 // geopotential_t as one batched launch.  Same kernels' bodies, same results bit for bit; 5 launches instead of 9.
 struct ZmTailSmall {
     int ncol, pver, pcols, dycore_kind;
+    int rz_uniform;                                   // rair / zvir point at ONE value each (stride 0) instead of fields
     double ztodt, qmin;
     // geopotential_t inputs of the state (pressure fields are the caller's, unchanged by the path)
     const double *lnpint, *pint, *pmid, *pdel, *rpdel, *rair, *zvir;

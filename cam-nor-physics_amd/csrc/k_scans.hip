@@ -87,8 +87,10 @@ __device__ __forceinline__ void geopotential_body(int bid, int tid, int nt, doub
                                                   const double *__restrict__ rpdel, const double *__restrict__ t,
                                                   const double *__restrict__ q, const double *__restrict__ rair,
                                                   double gravit, const double *__restrict__ zvir,
-                                                  double *__restrict__ zi, double *__restrict__ zm)
+                                                  double *__restrict__ zi, double *__restrict__ zm, size_t rzs)
 {
+    // rzs: stride of rair / zvir, 1 = fields [ncol][pver] (rairv, zvirv of physics_types.F90:393-415), 0 = ONE value each --
+    // what they hold without WACCM-X; the two reads then cost no HBM traffic (2 of the FV branch's 9 streams)
     const int col0 = bid * GT;
     const int nc = min(GT, ncol - col0);
     const int pverp = pver + 1;
@@ -117,11 +119,11 @@ __device__ __forceinline__ void geopotential_body(int bid, int tid, int nt, doub
             qfac = 1.0 / qfac;
             for (int idx = 0; idx < nspecies; ++idx) sum_dry = sum_dry + q[idx * F + g] * qfac;
             sum_dry = 1.0 / sum_dry;
-            tvfac = (1.0 + (zvir[g] + 1.0) * q1 * qfac) * sum_dry;
+            tvfac = (1.0 + (zvir[g * rzs] + 1.0) * q1 * qfac) * sum_dry;
         } else {
-            tvfac = 1.0 + zvir[g] * q1;                        // :241
+            tvfac = 1.0 + zvir[g * rzs] * q1;                  // :241
         }
-        const double rog = rair[g] / gravit;                   // :203
+        const double rog = rair[g * rzs] / gravit;             // :203
         const double tv = t[g] * tvfac;
         sZM[c * ldp + k] = rog * tv * hkk;                     // :244
         sZI[c * ldp + k] = rog * tv * hkl;                     // :245
@@ -156,12 +158,12 @@ __global__ __launch_bounds__(GNT) void geopotential_kernel(int ncol, int pver, i
                                                          const double *__restrict__ rpdel, const double *__restrict__ t,
                                                          const double *__restrict__ q, const double *__restrict__ rair,
                                                          double gravit, const double *__restrict__ zvir,
-                                                         double *__restrict__ zi, double *__restrict__ zm)
+                                                         double *__restrict__ zi, double *__restrict__ zm, size_t rzs)
 {
     CHAIN_PRIO();
     extern __shared__ double smem[];
     geopotential_body(blockIdx.x, threadIdx.x, GNT, smem, ncol, pver, dycore_kind, nspecies, piln, pint, pmid, pdel, rpdel, t, q, rair, gravit,
-                      zvir, zi, zm);
+                      zvir, zi, zm, rzs);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -800,7 +802,7 @@ __global__ __launch_bounds__(MOM_WAVES * WAVE) void momtran_wave_kernel(ZmDev P,
 // [0, ng) geopotential_t tiles, [ng, ng + ne) zm_conv_evap tiles, the rest one momtran block per host chunk -- each running
 // the body of the stand-alone kernel.  ENT threads per block; the dynamic LDS is the largest of the three.
 // ------------------------------------------------------------------------------------------------------
-struct Tail3Geo { int dycore_kind; const double *piln, *pint, *pmid, *pdel, *rpdel, *t, *q, *rair, *zvir; double gravit; double *zi, *zm; };
+struct Tail3Geo { int dycore_kind; const double *piln, *pint, *pmid, *pdel, *rpdel, *t, *q, *rair, *zvir; double gravit; double *zi, *zm; size_t rzs; };
 __global__ __launch_bounds__(ENT) void zm_tail3_kernel(ZmDev P, const double *__restrict__ estbl, int ncol, int pver, int pcols, int ng, int ne,
                                                      Tail3Geo G, double ztodt, colphys_zm_conv_evap_io E, colphys_momtran_io M,
                                                      const double *winds_v)
@@ -811,7 +813,7 @@ __global__ __launch_bounds__(ENT) void zm_tail3_kernel(ZmDev P, const double *__
     const int b = blockIdx.x;                                   // block-uniform dispatch
     if (b < ng)
         geopotential_body(b, threadIdx.x, ENT, smem, ncol, pver, G.dycore_kind, 1, G.piln, G.pint, G.pmid, G.pdel, G.rpdel, G.t, G.q, G.rair,
-                          G.gravit, G.zvir, G.zi, G.zm);
+                          G.gravit, G.zvir, G.zi, G.zm, G.rzs);
     else if (b < ng + ne)
         zm_conv_evap_body(b - ng, smem, s_estbl, P, estbl, ncol, pver, ztodt, E);
     else
@@ -851,13 +853,13 @@ __global__ __launch_bounds__(GNT) void geopotential_pair_kernel(int ncol, int pv
                                                               const double *__restrict__ t_a, const double *__restrict__ t_b,
                                                               const double *__restrict__ q, const double *__restrict__ rair, double gravit,
                                                               const double *__restrict__ zvir, double *zi_a, double *zm_a, double *zi_b,
-                                                              double *zm_b)
+                                                              double *zm_b, size_t rzs)
 {
     CHAIN_PRIO();
     extern __shared__ double smem[];
     const bool second = blockIdx.y != 0;
     geopotential_body(blockIdx.x, threadIdx.x, GNT, smem, ncol, pver, dycore_kind, 1, piln, pint, pmid, pdel, rpdel, second ? t_b : t_a, q, rair,
-                      gravit, zvir, second ? zi_b : zi_a, second ? zm_b : zm_a);
+                      gravit, zvir, second ? zi_b : zi_a, second ? zm_b : zm_a, rzs);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -898,7 +900,7 @@ inline int set_lds(const void *fn, size_t bytes)
 int launch_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspecies, const double *piln,
                           const double *pint, const double *pmid, const double *pdel, const double *rpdel,
                           const double *t, const double *q, const double *rair, double gravit, const double *zvir,
-                          double *zi, double *zm, hipStream_t st)
+                          double *zi, double *zm, hipStream_t st, int rz_uniform)
 {
     (void)nq;
     const int ldp = ((pver + 1) & 1) ? pver + 1 : pver + 2;
@@ -906,7 +908,7 @@ int launch_geopotential_t(int ncol, int pver, int dycore_kind, int nq, int nspec
     if (set_lds((const void *)geopotential_kernel, lds)) return COLPHYS_ERR_HIP;
     const int nblk = (ncol + GT - 1) / GT;
     hipLaunchKernelGGL(geopotential_kernel, dim3(nblk), dim3(GNT), lds, st, ncol, pver, dycore_kind, nspecies, piln, pint,
-                       pmid, pdel, rpdel, t, q, rair, gravit, zvir, zi, zm);
+                       pmid, pdel, rpdel, t, q, rair, gravit, zvir, zi, zm, (size_t)(rz_uniform ? 0 : 1));
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
 
@@ -956,7 +958,8 @@ int launch_zm_tail_small(const ZmDev &P, const double *estbl_dev, const ZmTailSm
     if (lds > 150 * 1024) return COLPHYS_ERR_UNSUPPORTED;
     if (set_lds((const void *)zm_tail3_kernel, lds)) return COLPHYS_ERR_HIP;
     const int ng = (ncol + GT - 1) / GT, ne = (ncol + ETILE - 1) / ETILE, nm = (ncol + T.pcols - 1) / T.pcols;
-    Tail3Geo G{T.dycore_kind, T.lnpint, T.pint, T.pmid, T.pdel, T.rpdel, T.t1, T.q1, T.rair, T.zvir, P.gravit, T.zi1, T.zm1};
+    const size_t rzs = T.rz_uniform ? 0 : 1;
+    Tail3Geo G{T.dycore_kind, T.lnpint, T.pint, T.pmid, T.pdel, T.rpdel, T.t1, T.q1, T.rair, T.zvir, P.gravit, T.zi1, T.zm1, rzs};
     hipLaunchKernelGGL(zm_tail3_kernel, dim3(ng + ne + nm), dim3(ENT), lds, st, P, estbl_dev, ncol, pver, T.pcols, ng, ne, G, T.ztodt, T.evap,
                        T.mom, T.v);
     const size_t n = (size_t)ncol * pver;
@@ -965,7 +968,7 @@ int launch_zm_tail_small(const ZmDev &P, const double *estbl_dev, const ZmTailSm
                        T.evap.tend_q, T.mom.seten, T.u, T.v, T.mom.dqdt, T.mom.dqdt + n, T.u1, T.v1, T.ptend_s, T.ptend_q, T.ptend_u, T.ptend_v);
     if (set_lds((const void *)geopotential_pair_kernel, lds_geo)) return COLPHYS_ERR_HIP;
     hipLaunchKernelGGL(geopotential_pair_kernel, dim3(ng, 2), dim3(GNT), lds_geo, st, ncol, pver, T.dycore_kind, T.lnpint, T.pint, T.pmid, T.pdel,
-                       T.rpdel, T.t2, T.t1, T.q1, T.rair, P.gravit, T.zvir, T.zi_scratch, T.zm_scratch, T.zi1, T.zm1);
+                       T.rpdel, T.t2, T.t1, T.q1, T.rair, P.gravit, T.zvir, T.zi_scratch, T.zm_scratch, T.zi1, T.zm1, rzs);
     return (hipGetLastError() == hipSuccess) ? COLPHYS_OK : COLPHYS_ERR_HIP;
 }
 

@@ -228,12 +228,14 @@ class ColumnPhysics:
         return o
 
     def zm_conv_tend(self, state: dict, ztodt, pcols=16, dycore=abi.DYCORE_FV, qmin=1.0e-12, out=None, hist=False):
-        """state: device tensors named as abi.ZM_TEND_IN; returns ptend_all, the pbuf fields, diagnostics and state1
+        """state: device tensors named as abi.ZM_TEND_IN (rair / zvir may be absent: uniform); returns ptend_all, the pbuf fields, diagnostics and state1
         (hist: and the history / argument outputs of abi.ZM_TEND_HIST)."""
         n, pver = state["t"].shape
         o = self.alloc_zm_conv_tend_out(n, pver, pcols, hist) if out is None else out
         io = abi.ZmConvTendIO()
         for k in abi.ZM_TEND_IN:
+            if k in ("rair", "zvir") and state.get(k) is None:
+                continue                        # NULL: the engine's own constants (no WACCM-X; include/colphys.h)
             setattr(io, k, _p(self._f64(state[k])))
         for k, v in o.items():
             setattr(io, k, _p(v, abi.PI) if v.dtype == self.torch.int32 else _p(v))

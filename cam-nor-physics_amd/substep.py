@@ -16,14 +16,14 @@ import numpy as np
 from . import abi, synth
 
 STATE_FIELDS = ("t", "q", "u", "v", "pint", "pmid", "pdel", "rpdel", "lnpint", "lnpmid", "pdeldry", "phis", "pblh", "tpert",
-                "landfrac", "cld", "rair", "zvir", "zi", "zm")
+                "landfrac", "cld", "zi", "zm")
 
 
 class ResidentSubstep:
     """st / aer / props: host dictionaries of cam_nor_physics_amd.synth for THIS rank's columns."""
 
     def __init__(self, eng, st, aer=None, props=None, *, pcols=16, sw_diag=True, two_streams=True, lw_kernel="auto",
-                 dt=synth.ZTODT):
+                 dt=synth.ZTODT, rz_fields=False):
         import torch
         self.torch = torch
         self.eng = eng
@@ -33,6 +33,11 @@ class ResidentSubstep:
         self.sw_diag = self.with_aero and sw_diag
         d = eng.dev
         self.S = {k: d(st[k]) for k in STATE_FIELDS}
+        # rairv / zvirv (physics_types.F90:393-415) hold ONE value each unless WACCM-X varies the composition: the engine's
+        # own constants serve (NULL fields, include/colphys.h); rz_fields=True uploads the two [ncol][pver] fields instead
+        # (same bits, two more streams per geopotential_t)
+        if rz_fields:
+            self.S["rair"], self.S["zvir"] = d(st["rair"]), d(st["zvir"])
         self.S["ps"] = d(np.ascontiguousarray(st["pint"][:, -1]))
         self.zm_out = eng.alloc_zm_conv_tend_out(self.ncol, self.pver, pcols)
         self.side = None

@@ -131,6 +131,9 @@ int  colphys_finalize(void);
  * geopotential_t  (geopotential.F90:153-156)
  *   q is [nq][ncol][pver]; species 0 is water vapour; for COLPHYS_DYCORE_SE the first `nspecies`
  *   entries are the thermodynamically active species (air_composition).
+ *   rair, zvir ([ncol][pver]: rairv, zvirv of physics_types.F90:393-415) may BOTH be NULL in the _dev entry: the engine then uses
+ *   the rair / zvir of colphys_zm_params for every cell -- what the two fields hold everywhere unless WACCM-X varies the
+ *   composition -- and the kernel reads two streams less (same bits as fields filled with those constants).
  * ------------------------------------------------------------------------------------------------- */
 int colphys_geopotential_t_dev(int ncol, int pver, int dycore_kind, int nq, int nspecies,
                                const double *piln, const double *pmln, const double *pint,
@@ -495,7 +498,7 @@ typedef struct colphys_zm_conv_tend_io {
     /* physics_state */
     const double *t, *q, *u, *v, *pmid, *pint, *pdel, *rpdel, *lnpint, *lnpmid, *zm, *zi;
     const double *phis, *ps;                 /* [ncol] */
-    const double *rair, *zvir;               /* [ncol][pver], as geopotential_t takes them */
+    const double *rair, *zvir;               /* [ncol][pver], as geopotential_t takes them; or both NULL: the engine's constants */
     const double *pblh, *tpert, *landfrac;   /* [ncol] */
     const double *cld;                       /* [ncol][pver], pbuf CLD at the old time level (:585) */
     /* ptend_all */

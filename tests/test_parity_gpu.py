@@ -1264,6 +1264,38 @@ def test_zm_conv_tend_fused_tail_equals_separate_launches(pver, ncol, monkeypatc
         assert a["lengath"].sum() > 0 and np.abs(a["ptend_u"]).max() > 0 and np.abs(a["evapcdp"]).max() > 0
 
 
+@pytest.mark.parametrize("pver,ncol", [(32, 6075), (70, 777), (32, 30011)])
+def test_uniform_rair_zvir_equal_the_fields(pver, ncol, monkeypatch):
+    """rairv / zvirv hold one value each unless WACCM-X varies the composition (physics_types.F90:393-415): NULL for both fields
+    makes the engine use its own constants -- two streams less per geopotential_t -- with the same bits as fields filled with
+    them: geopotential_t of all three dycore branches, zm_conv_tend with the staged and with the fused tail; one of the two alone
+    is an argument error"""
+    eng = engine(cases.default_params(pver))
+    st = synth.make_state(ncol, pver, 2024, moist_boost=1.1)
+    d = eng.dev
+    c = synth.PHYSCONST
+    assert np.all(st["rair"] == c["rair"]) and np.all(st["zvir"] == c["zvir"])
+    ga = [d(x) for x in cases.geo_args(st)[:6]]
+    for dycore in (abi.DYCORE_EUL, abi.DYCORE_FV, abi.DYCORE_SE):
+        a = eng.geopotential_t(*ga, d(st["t"]), d(st["q"]), d(st["rair"]), c["gravit"], d(st["zvir"]), dycore=dycore)
+        b = eng.geopotential_t(*ga, d(st["t"]), d(st["q"]), None, c["gravit"], None, dycore=dycore)
+        assert eng.torch.equal(a[0], b[0]) and eng.torch.equal(a[1], b[1]), dycore
+    with pytest.raises(RuntimeError):
+        eng.geopotential_t(*ga, d(st["t"]), d(st["q"]), d(st["rair"]), c["gravit"], None)
+    S = {k: d(st[k]) for k in abi.ZM_TEND_IN if k != "ps"}
+    S["ps"] = d(st["pint"][:, -1].copy())
+    U = {k: v for k, v in S.items() if k not in ("rair", "zvir")}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("COLPHYS_TAIL_FUSED", fused)
+        a = to_np(eng.zm_conv_tend(S, synth.ZTODT, hist=True))
+        b = to_np(eng.zm_conv_tend(U, synth.ZTODT, hist=True))
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (fused, k)
+    U["rair"] = S["rair"]
+    with pytest.raises(RuntimeError):
+        eng.zm_conv_tend(U, synth.ZTODT)
+
+
 def test_lane_quads_pairs_and_single_lanes_give_the_same_bits(monkeypatch):
     """The dilute ascents with one, two or four lanes per column (colphys_common.h: lane pairs split the independent
     transcendentals of a function evaluation, lane quads also run the two opening evaluations of every inversion side by side)
