@@ -43,6 +43,17 @@ for r in range(nreg):
     args = cases.zm_args_from_state(st, zi_r, zm_r)
     ref = co.zm_convr(*args)
     o = T.run_zm(eng, args)
+    if os.environ.get("STRESS_ONLY"):                       # one regime under the lens: where and how big, before anything asserts
+        for k in ("cape",):
+            a_, b_ = np.asarray(o[k]), np.asarray(ref[k])
+            i_ = int(np.argmax(np.abs(a_ - b_) / np.maximum(np.abs(b_), 1e-300)))
+            print(f"   {k}: largest relative difference at column {i_}: hip {a_[i_]!r} ref {b_[i_]!r} (|diff| {abs(a_[i_] - b_[i_]):.3e}, field max "
+                  f"{np.abs(b_).max():.3e})")
+        for lpc in ("1", "2", "4"):
+            os.environ["COLPHYS_LPC_TRIG"] = lpc; os.environ["COLPHYS_LPC_ASC"] = lpc
+            ol = T.run_zm(eng, args)
+            print(f"   lanes per column {lpc}: cape identical to the default run: {np.array_equal(ol['cape'], o['cape'])}")
+        os.environ.pop("COLPHYS_LPC_TRIG"); os.environ.pop("COLPHYS_LPC_ASC")
     worst = T.check_zm(o, ref, ncol)
     if os.environ.get("STRESS_ONLY"):
         from util import rel_err_profile
