@@ -18,6 +18,7 @@ from cam_nor_physics_amd import abi, synth
 rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "7")))
 nreg = int(os.environ.get("STRESS_REGIMES", "24"))
 worst_all = 0.0
+over = 0
 for r in range(nreg):
     pver = int(rng.choice([26, 30, 32, 33, 47, 70]))
     ncol = int(rng.integers(200, 1500))
@@ -54,7 +55,12 @@ for r in range(nreg):
             ol = T.run_zm(eng, args)
             print(f"   lanes per column {lpc}: cape identical to the default run: {np.array_equal(ol['cape'], o['cape'])}")
         os.environ.pop("COLPHYS_LPC_TRIG"); os.environ.pop("COLPHYS_LPC_ASC")
-    worst = T.check_zm(o, ref, ncol)
+    try:
+        worst = T.check_zm(o, ref, ncol)
+    except AssertionError as ex:                            # keep going: report every regime over the bar, fail at the end
+        print(f"regime {r}: OVER THE BAR in zm_convr: {ex}", flush=True)
+        over += 1
+        continue
     if os.environ.get("STRESS_ONLY"):
         from util import rel_err_profile
         m_ = T.gathered_mask(ref["lengath"], ncol, 16)
@@ -84,4 +90,5 @@ for r in range(nreg):
     worst_all = max(worst_all, worst)
     print(f"regime {r:2d}: L{pver} {ncol:4d} cols deep {int(ref['lengath'].sum()):4d} pbl={nl['parcel_pbl']} nodeep={nl['no_deep_pbl']} "
           f"ncin={nl['num_cin']} tiedke={nl['tiedke_add']} capelmt={nl['capelmt']:.0f} Ts={ts} RH={rh}: worst {worst:.2e}", flush=True)
-print(f"worst over {nreg} regimes: {worst_all:.2e}")
+print(f"worst over {nreg} regimes: {worst_all:.2e}" + (f"; {over} regime(s) over the bar" if over else ""))
+sys.exit(1 if over else 0)
