@@ -196,6 +196,7 @@ def parse_args(argv=None):
                     help="kernel family of modal_aero_lw (colphys_aero_kernel_select).  auto = bands-outer: with the SW diagnostics "
                          "in the substep the optics stream ends last and the kernel that is faster alone wins (2.425 against 2.453 ms); "
                          "with --no-sw-diag `grouped` measures 0.6 %% faster")
+    ap.add_argument("--lw-first", action="store_true", help="A/B: modal_aero_lw ahead of modal_aero_sw on the optics stream")
     ap.add_argument("--serial", action="store_true", help="all kernels on one stream (no ZM || optics overlap)")
     return ap.parse_args(argv)
 
@@ -333,7 +334,7 @@ def main():
                 raise SystemExit("graph replay and eager launches disagree")
         return elapsed, total_cols
 
-    ss = ResidentSubstep(eng, st, aer, props, pcols=pcols, sw_diag=sw_diag, two_streams=not args.serial, lw_kernel=args.lw_kernel)
+    ss = ResidentSubstep(eng, st, aer, props, pcols=pcols, sw_diag=sw_diag, two_streams=not args.serial, lw_kernel=args.lw_kernel, lw_first=args.lw_first)
     elapsed, total_cols = timed_pass(ss)
 
     # ---- per-kernel durations: HIP events on the launch stream, in a separate short pass ------------------
@@ -364,7 +365,7 @@ def main():
         torch.cuda.empty_cache()
         other = "strong" if headline == "weak" else "weak"
         st2, aer2 = workload(other)
-        ss2 = ResidentSubstep(eng, st2, aer2, props, pcols=pcols, sw_diag=sw_diag, two_streams=not args.serial, lw_kernel=args.lw_kernel)
+        ss2 = ResidentSubstep(eng, st2, aer2, props, pcols=pcols, sw_diag=sw_diag, two_streams=not args.serial, lw_kernel=args.lw_kernel, lw_first=args.lw_first)
         e2, c2 = timed_pass(ss2)
         second = {"scaling": other, "value": round(c2 * args.steps / e2, 1), "unit": "columns/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
                   "columns_per_rank": gather_ints(ss2.ncol), "total_columns": int(c2)}

@@ -23,7 +23,7 @@ class ResidentSubstep:
     """st / aer / props: host dictionaries of cam_nor_physics_amd.synth for THIS rank's columns."""
 
     def __init__(self, eng, st, aer=None, props=None, *, pcols=16, sw_diag=True, two_streams=True, lw_kernel="auto",
-                 dt=synth.ZTODT, rz_fields=False):
+                 dt=synth.ZTODT, rz_fields=False, lw_first=False):
         import torch
         self.torch = torch
         self.eng = eng
@@ -31,6 +31,7 @@ class ResidentSubstep:
         self.pcols, self.dt = pcols, dt
         self.with_aero = aer is not None
         self.sw_diag = self.with_aero and sw_diag
+        self.lw_first = lw_first                        # A/B: modal_aero_lw ahead of modal_aero_sw on the optics stream
         d = eng.dev
         self.S = {k: d(st[k]) for k in STATE_FIELDS}
         # rairv / zvirv (physics_types.F90:393-415) hold ONE value each unless WACCM-X varies the composition: the engine's
@@ -65,11 +66,14 @@ class ResidentSubstep:
     # ---- the launches of one substep, on the current stream (+ the side stream) -------------------------------------
     def optics(self):
         eng, S, A = self.eng, self.S, self.A
+        if self.lw_first:
+            eng.modal_aero_lw(S["pdeldry"], A["specmmr"], A["dgnumwet"], A["qaerwat"], out=self.lw_out)
         eng.modal_aero_sw(S["pdeldry"], A["specmmr"], A["dgnumwet"], A["qaerwat"], out=self.sw_out, vis=self.swd_vis if self.sw_diag else None)
         if self.sw_diag:                                # what the reference's modal_aero_sw also computes, for outfld
             eng.modal_aero_sw_diag(S["pdeldry"], S["pmid"], S["t"], A["specmmr"], A["dgnumwet"], A["qaerwat"], A["troplevchem"],
                                    self.sw_out["tauxar"], out=self.swd_out, vis=self.swd_vis)
-        eng.modal_aero_lw(S["pdeldry"], A["specmmr"], A["dgnumwet"], A["qaerwat"], out=self.lw_out)
+        if not self.lw_first:
+            eng.modal_aero_lw(S["pdeldry"], A["specmmr"], A["dgnumwet"], A["qaerwat"], out=self.lw_out)
 
     def launch(self, overlap=True):
         """eager launches; overlap=False puts everything on the current stream (per-kernel timing passes)"""
